@@ -1,0 +1,136 @@
+"""ctypes binding of libgsr_hip.so (C ABI: include/gsr.h).
+
+There is deliberately no fallback: if the HIP library has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or `make -C gaussmart_amd/csrc`) loading
+raises, and every operator in this package raises with it.
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgsr_hip.so")
+ABI_VERSION = 1
+
+GSR_BUF_GEOM, GSR_BUF_BINNING, GSR_BUF_IMAGE, GSR_BUF_SCRATCH, GSR_BUF_SCRATCH2 = range(5)
+GSR_FLAG_CLAMP_PASSTHROUGH = 1
+GSR_FLAG_FILTER_DEPTH_GRAD = 2
+GSR_FLAGS_UPSTREAM = 3
+
+KERNEL_NAMES = ("preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
+                "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn")
+
+
+class GsrView(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32),
+                ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+                ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32), ("channels", C.c_int32),
+                ("flags", C.c_uint32),
+                ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+                ("campos", C.c_void_p)]
+
+
+class GsrGaussians(C.Structure):
+    _fields_ = [("count", C.c_int32),
+                ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+                ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
+                ("transmat_precomp", C.c_void_p)]
+
+
+class GsrForwardOut(C.Structure):
+    _fields_ = [("out_color", C.c_void_p), ("out_allmap", C.c_void_p), ("radii", C.c_void_p),
+                ("num_rendered", C.c_int32),
+                ("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p)]
+
+
+class GsrGrads(C.Structure):
+    _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dopacity", C.c_void_p),
+                ("dL_dshs", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_dscales", C.c_void_p),
+                ("dL_drotations", C.c_void_p), ("dL_dtransmat", C.c_void_p)]
+
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
+
+_lock = threading.Lock()
+_lib = None
+
+
+class GsrError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (loads on first use).  Raises if it is missing or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise GsrError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C gaussmart_amd/csrc`). "
+                "gaussmart_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.gsr_abi_version.restype = C.c_int32
+        L.gsr_last_error.restype = C.c_char_p
+        if L.gsr_abi_version() != ABI_VERSION:
+            raise GsrError(f"libgsr_hip.so ABI {L.gsr_abi_version()} != expected {ABI_VERSION}; rebuild")
+        L.gsr_forward.restype = C.c_int32
+        L.gsr_forward.argtypes = [C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrForwardOut),
+                                  ALLOC_FN, C.c_void_p, C.c_void_p]
+        L.gsr_backward.restype = C.c_int32
+        L.gsr_backward.argtypes = [C.POINTER(GsrView), C.POINTER(GsrGaussians), C.c_int32, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(GsrGrads), ALLOC_FN, C.c_void_p, C.c_void_p]
+        L.gsr_buffer_field.restype = C.c_int32
+        L.gsr_buffer_field.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.gsr_knn3_workspace_bytes.restype = C.c_size_t
+        L.gsr_knn3_workspace_bytes.argtypes = [C.c_int32]
+        L.gsr_knn3.restype = C.c_int32
+        L.gsr_knn3.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gsr_sort_workspace_bytes.restype = C.c_size_t
+        L.gsr_sort_workspace_bytes.argtypes = [C.c_int32]
+        L.gsr_sort_pairs_u32.restype = C.c_int32
+        L.gsr_sort_pairs_u32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gsr_profile_enable.restype = None
+        L.gsr_profile_enable.argtypes = [C.c_int32]
+        L.gsr_profile_reset.restype = None
+        L.gsr_profile_read.restype = C.c_int32
+        L.gsr_profile_read.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = lib().gsr_last_error().decode("utf-8", "replace")
+        # argument-combination errors surface as plain Exception text the reference's callers expect
+        raise GsrError(f"libgsr_hip error {rc}: {msg}")
+
+
+def buffer_field(which: int, name: str, N: int, D: int, W: int, H: int):
+    off, nbytes = C.c_size_t(), C.c_size_t()
+    check(lib().gsr_buffer_field(which, name.encode(), N, D, W, H, C.byref(off), C.byref(nbytes)))
+    return off.value, nbytes.value
+
+
+def profile_enable(on: bool):
+    lib().gsr_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    lib().gsr_profile_reset()
+
+
+def profile_read():
+    """{kernel: (total_ms, launches)} accumulated since the last reset (synchronises the events)."""
+    out = {}
+    for k in KERNEL_NAMES:
+        ms, n = C.c_double(), C.c_int32()
+        check(lib().gsr_profile_read(k.encode(), C.byref(ms), C.byref(n)))
+        out[k] = (ms.value, n.value)
+    return out

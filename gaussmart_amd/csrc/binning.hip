@@ -1,0 +1,391 @@
+// K2-K5 binning: exclusive scan, stable LSD radix sort of (u32 key, u32 value) pairs, instance
+// emission and per-tile ranges.
+//
+// The recalled upstream sorts D (Gaussian, tile) pairs by the 64-bit key (tile << 32 | depth bits)
+// in one ~6-pass radix sort.  The same final order is obtained here with far less traffic:
+//   1. stable sort of the N Gaussians by depth bits (culled ones get key 0xFFFFFFFF),
+//   2. instances are emitted in that order (tiles row-major inside a rect),
+//   3. a stable sort of the D instances by tile id only (ceil(log2 tiles) bits, 2 passes).
+// Stability makes ties fall back to emission order = (depth, Gaussian index), which is exactly the
+// order a stable sort of the 64-bit keys emitted in Gaussian-index order produces, so
+// `point_list` is bit-identical (checked against NumPy's stable argsort in tests/test_binning.py).
+//
+// All integer work; HBM-bound.  Wave64 throughout: digit matching uses 64-bit ballots.
+#include "gsr_common.h"
+
+// ============================================================================ scan
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t n = __shfl_up(v, d, 64);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread across a 256-thread block; returns block total
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total, uint32_t* wave_tot /*[4+]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan(v, lane);
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
+        const uint32_t t = wave_tot[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_reduce_kernel(const uint32_t* __restrict__ in,
+                                                                 const uint32_t* __restrict__ gather,
+                                                                 uint32_t* __restrict__ partial, int64_t n) {
+    __shared__ uint32_t wt[SCAN_BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = base + (int64_t)i * SCAN_BLOCK + threadIdx.x;
+        if (j < n) sum += gather ? in[gather[j]] : in[j];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
+    if ((threadIdx.x & 63) == 0) wt[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = wt[0] + wt[1] + wt[2] + wt[3];
+}
+
+// single block: exclusive scan of the block partials in place
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_partials_kernel(uint32_t* __restrict__ partial, int n) {
+    __shared__ uint32_t wt[SCAN_BLOCK / 64];
+    uint32_t carry = 0;
+    for (int base = 0; base < n; base += SCAN_BLOCK) {
+        const int j = base + threadIdx.x;
+        const uint32_t v = j < n ? partial[j] : 0;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(v, total, wt);
+        if (j < n) partial[j] = carry + ex;
+        carry += total;
+    }
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const uint32_t* __restrict__ in,
+                                                                const uint32_t* __restrict__ gather,
+                                                                const uint32_t* __restrict__ partial,
+                                                                uint32_t* __restrict__ out, int64_t n) {
+    __shared__ uint32_t wt[SCAN_BLOCK / 64];
+    // thread owns SCAN_ITEMS consecutive elements so the block tile is scanned in index order
+    const int64_t first = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = first + i;
+        v[i] = j < n ? (gather ? in[gather[j]] : in[j]) : 0;
+        tsum += v[i];
+    }
+    uint32_t total;
+    uint32_t run = partial[blockIdx.x] + block_excl_scan(tsum, total, wt);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = first + i;
+        if (j < n) out[j] = run;
+        run += v[i];
+    }
+    // grand total lands in out[n]
+    if (first <= n - 1 && n - 1 < first + SCAN_ITEMS) out[n] = run;
+}
+
+size_t gsr_scan_workspace_bytes(int64_t n) {
+    const int64_t blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+    return gsr_align(size_t(blocks > 0 ? blocks : 1) * 4);
+}
+
+int gsr_exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
+                           void* ws, hipStream_t s) {
+    if (n <= 0) {
+        GSR_HIP_CHECK(hipMemsetAsync(out, 0, 4, s));
+        return GSR_OK;
+    }
+    GsrProfileScope prof(GSR_K_SCAN, s);
+    uint32_t* partial = static_cast<uint32_t*>(ws);
+    const int blocks = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, s, in, gather, partial, n);
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, partial, blocks);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, s, in, gather, partial, out, n);
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}
+
+// ============================================================================ radix sort
+#define RS_BLOCK 256
+#define RS_WAVES (RS_BLOCK / 64)
+#define RS_ITEMS 16
+#define RS_TILE (RS_BLOCK * RS_ITEMS)   // 4096 pairs per workgroup
+#define RS_MAX_BINS 256
+
+__global__ void __launch_bounds__(RS_BLOCK) rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t n,
+                                                           int shift, uint32_t mask, int nbins,
+                                                           int nblocks, uint32_t* __restrict__ table) {
+    __shared__ uint32_t hist[RS_MAX_BINS];
+    for (int i = threadIdx.x; i < nbins; i += RS_BLOCK) hist[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const int64_t j = base + (int64_t)i * RS_BLOCK + threadIdx.x;
+        if (j < n) atomicAdd(&hist[(keys[j] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    // digit-major table: an exclusive scan over it is the global base of (digit, block)
+    for (int i = threadIdx.x; i < nbins; i += RS_BLOCK) table[(size_t)i * nblocks + blockIdx.x] = hist[i];
+}
+
+template <int BITS>
+__global__ void __launch_bounds__(RS_BLOCK) rs_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                              const uint32_t* __restrict__ vals_in,
+                                                              uint32_t* __restrict__ keys_out,
+                                                              uint32_t* __restrict__ vals_out, int64_t n,
+                                                              int shift, int nblocks,
+                                                              const uint32_t* __restrict__ table_scanned) {
+    constexpr int NB = 1 << BITS;
+    constexpr uint32_t MASK = NB - 1;
+    __shared__ uint32_t wave_hist[RS_WAVES][NB];
+    __shared__ uint32_t digit_start[NB];   // start of each digit in the block-local sorted order
+    __shared__ uint32_t gbase[NB];         // global base of (digit, this block)
+    __shared__ uint32_t s_keys[RS_TILE];
+    __shared__ uint32_t s_vals[RS_TILE];
+    __shared__ uint32_t wt[RS_WAVES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < RS_WAVES * NB; i += RS_BLOCK) (&wave_hist[0][0])[i] = 0;
+    for (int i = tid; i < NB; i += RS_BLOCK) gbase[i] = table_scanned[(size_t)i * nblocks + blockIdx.x];
+    __syncthreads();
+
+    const int64_t block_base = (int64_t)blockIdx.x * RS_TILE;
+    const int block_n = (int)min((int64_t)RS_TILE, n - block_base);
+    const int wave_base_idx = wave * (RS_TILE / RS_WAVES);
+
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const int local = wave_base_idx + r * 64 + lane;   // index order = (wave, round, lane)
+        const bool valid = local < block_n;
+        key[r] = valid ? keys_in[block_base + local] : 0xFFFFFFFFu;
+        // vals_in == NULL means "values are the element indices" (first pass of an argsort)
+        val[r] = valid ? (vals_in ? vals_in[block_base + local] : (uint32_t)(block_base + local)) : 0u;
+        const uint32_t d = (key[r] >> shift) & MASK;
+        // lanes holding the same digit (among valid lanes)
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < BITS; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            same &= bit ? bal : ~bal;
+        }
+        const uint32_t before = __popcll(same & lt_mask);
+        const uint32_t count = __popcll(same);
+        const bool last = valid && ((same >> lane) >> 1) == 0ull;
+        uint32_t pre = 0;
+        if (valid) pre = wave_hist[wave][d];
+        rank[r] = pre + before;
+        __builtin_amdgcn_wave_barrier();
+        if (last) wave_hist[wave][d] = pre + count;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+
+    // per digit: exclusive prefix over waves, block totals, then exclusive scan over digits
+    uint32_t my_total = 0;
+    if (tid < NB) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) {
+            const uint32_t c = wave_hist[w][tid];
+            wave_hist[w][tid] = run;
+            run += c;
+        }
+        my_total = run;
+    }
+    uint32_t tot_unused;
+    const uint32_t ex = block_excl_scan(my_total, tot_unused, wt);
+    if (tid < NB) digit_start[tid] = ex;
+    __syncthreads();
+
+    // block-local reorder through LDS so the global writes are runs of consecutive addresses
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const int local = wave_base_idx + r * 64 + lane;
+        if (local < block_n) {
+            const uint32_t d = (key[r] >> shift) & MASK;
+            const uint32_t pos = digit_start[d] + wave_hist[wave][d] + rank[r];
+            s_keys[pos] = key[r];
+            s_vals[pos] = val[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const int pos = i * RS_BLOCK + tid;
+        if (pos < block_n) {
+            const uint32_t k = s_keys[pos];
+            const uint32_t d = (k >> shift) & MASK;
+            const size_t g = (size_t)gbase[d] + (uint32_t)(pos - digit_start[d]);
+            keys_out[g] = k;
+            vals_out[g] = s_vals[pos];
+        }
+    }
+}
+
+__global__ void iota_kernel(uint32_t* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)i;
+}
+
+static size_t rs_table_entries(int64_t n) {
+    const int64_t nblocks = (n + RS_TILE - 1) / RS_TILE;
+    return size_t(nblocks > 0 ? nblocks : 1) * RS_MAX_BINS;
+}
+
+size_t gsr_sort_ws_bytes(int64_t n) {
+    // table (raw) + table (scanned, +1 for the total) + scan partials
+    const size_t e = rs_table_entries(n);
+    return gsr_align(e * 4) + gsr_align((e + 1) * 4) + gsr_scan_workspace_bytes((int64_t)e);
+}
+
+int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+                         uint32_t* vals_out, uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n,
+                         int begin_bit, int end_bit, void* ws, hipStream_t s) {
+    if (n <= 0) return GSR_OK;
+    const int bits = end_bit - begin_bit;
+    if (bits <= 0) {   // nothing to sort on: stable sort is the identity
+        GSR_HIP_CHECK(hipMemcpyAsync(keys_out, keys_in, size_t(n) * 4, hipMemcpyDeviceToDevice, s));
+        if (vals_in) GSR_HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, size_t(n) * 4, hipMemcpyDeviceToDevice, s));
+        else hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, vals_out, n);
+        GSR_LAUNCH_CHECK();
+        return GSR_OK;
+    }
+    const int passes = (bits + 7) / 8;
+    const int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
+    const size_t e = rs_table_entries(n);
+    uint32_t* table = static_cast<uint32_t*>(ws);
+    uint32_t* scanned = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + gsr_align(e * 4));
+    void* scan_ws = static_cast<char*>(ws) + gsr_align(e * 4) + gsr_align((e + 1) * 4);
+
+    // ping-pong so that the last pass lands in *_out
+    const uint32_t* src_k = keys_in; const uint32_t* src_v = vals_in;
+    int bit = begin_bit;
+    for (int p = 0; p < passes; ++p) {
+        const int remaining_passes = passes - p;
+        const int remaining_bits = end_bit - bit;
+        const int w = (remaining_bits + remaining_passes - 1) / remaining_passes;  // even split, <= 8
+        const int nbins = 1 << w;
+        const bool to_out = ((passes - 1 - p) % 2) == 0;
+        uint32_t* dst_k = to_out ? keys_out : keys_tmp;
+        uint32_t* dst_v = to_out ? vals_out : vals_tmp;
+        {
+            GsrProfileScope prof(GSR_K_SORT_HIST, s);
+            hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_BLOCK), 0, s, src_k, n, bit,
+                               (uint32_t)(nbins - 1), nbins, nblocks, table);
+        }
+        int rc = gsr_exclusive_scan_u32(table, nullptr, scanned, (int64_t)nbins * nblocks, scan_ws, s);
+        if (rc != GSR_OK) return rc;
+        {
+            GsrProfileScope prof(GSR_K_SORT_SCATTER, s);
+#define RS_CASE(B) case B: hipLaunchKernelGGL(rs_scatter_kernel<B>, dim3(nblocks), dim3(RS_BLOCK), 0, s, \
+                                              src_k, src_v, dst_k, dst_v, n, bit, nblocks, scanned); break;
+            switch (w) { RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
+                default: gsr_set_error("radix digit width %d", w); return GSR_E_INVALID; }
+#undef RS_CASE
+        }
+        GSR_LAUNCH_CHECK();
+        src_k = dst_k; src_v = dst_v;
+        bit += w;
+    }
+    return GSR_OK;
+}
+
+// ============================================================================ emit / finalize
+__global__ void __launch_bounds__(256) emit_instances_kernel(int N, int gx, int gy,
+                                                             const uint32_t* __restrict__ order,
+                                                             const uint32_t* __restrict__ offs,
+                                                             const float* __restrict__ splat,
+                                                             const int32_t* __restrict__ radii,
+                                                             const uint32_t* __restrict__ tiles_touched,
+                                                             uint32_t* __restrict__ inst_begin,
+                                                             uint32_t* __restrict__ tile_keys,
+                                                             uint32_t* __restrict__ inst_vals,
+                                                             uint32_t* __restrict__ emit_gid) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;   // depth rank
+    if (r >= N) return;
+    const uint32_t g = order[r];
+    const uint32_t cnt = tiles_touched[g];
+    uint32_t off = offs[r];
+    inst_begin[g] = off;
+    if (cnt == 0) return;
+    const float cx = splat[(size_t)g * GSR_SPLAT_FLOATS + GSR_SP_XY];
+    const float cy = splat[(size_t)g * GSR_SPLAT_FLOATS + GSR_SP_XY + 1];
+    int x0, y0, x1, y1;
+    gsr_tile_rect(cx, cy, radii[g], gx, gy, x0, y0, x1, y1);
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            tile_keys[off] = (uint32_t)(y * gx + x);
+            inst_vals[off] = off;
+            emit_gid[off] = g;
+            ++off;
+        }
+}
+
+int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const uint32_t* offs,
+                    const float* splat, const int32_t* radii, const uint32_t* tiles_touched,
+                    uint32_t* inst_begin, uint32_t* tile_keys, uint32_t* inst_vals,
+                    uint32_t* emit_gid, hipStream_t s) {
+    if (N <= 0) return GSR_OK;
+    GsrProfileScope prof(GSR_K_EMIT, s);
+    hipLaunchKernelGGL(emit_instances_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, grid_x, grid_y,
+                       order, offs, splat, radii, tiles_touched, inst_begin, tile_keys, inst_vals, emit_gid);
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}
+
+__global__ void __launch_bounds__(256) finalize_bins_kernel(int D, const uint32_t* __restrict__ tile_sorted,
+                                                            const uint32_t* __restrict__ perm,
+                                                            const uint32_t* __restrict__ emit_gid,
+                                                            uint32_t* __restrict__ point_list,
+                                                            uint32_t* __restrict__ inst_row,
+                                                            uint32_t* __restrict__ ranges) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    const uint32_t e = perm[i];
+    point_list[i] = emit_gid[e];
+    inst_row[i] = e;
+    const uint32_t t = tile_sorted[i];
+    if (i == 0) ranges[2 * t] = 0;
+    else {
+        const uint32_t tp = tile_sorted[i - 1];
+        if (tp != t) { ranges[2 * tp + 1] = i; ranges[2 * t] = i; }
+    }
+    if (i == D - 1) ranges[2 * t + 1] = D;
+}
+
+int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted, const uint32_t* perm,
+                             const uint32_t* emit_gid, uint32_t* point_list, uint32_t* inst_row,
+                             uint32_t* ranges, hipStream_t s) {
+    GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
+    if (D <= 0) return GSR_OK;
+    GsrProfileScope prof(GSR_K_FINALIZE, s);
+    hipLaunchKernelGGL(finalize_bins_kernel, dim3((D + 255) / 256), dim3(256), 0, s, D, tile_keys_sorted,
+                       perm, emit_gid, point_list, inst_row, ranges);
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}

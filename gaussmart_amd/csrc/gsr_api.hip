@@ -1,0 +1,314 @@
+// Host side of the C ABI declared in include/gsr.h: argument validation (mirrors the Python
+// operator's checks), buffer carving, kernel sequencing, error strings and the opt-in profiler.
+#include "gsr_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+// ------------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+void gsr_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* gsr_last_error(void) { return g_err; }
+extern "C" int32_t gsr_abi_version(void) { return GSR_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------- profiler
+namespace {
+struct KernelProf {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    hipEvent_t open = nullptr;
+    double total_ms = 0.0;
+    int launches = 0;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+KernelProf g_prof[GSR_K_COUNT];
+const char* const g_kernel_names[GSR_K_COUNT] = {
+    "preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
+    "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn"};
+constexpr size_t kMaxPending = 1 << 16;
+
+void prof_drain(KernelProf& k) {
+    for (auto& pr : k.pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pr.second) == hipSuccess &&
+            hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            k.total_ms += ms;
+            k.launches += 1;
+        }
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    k.pending.clear();
+}
+}  // namespace
+
+bool gsr_profile_on() { return g_prof_on; }
+void gsr_profile_begin(int kernel, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    KernelProf& k = g_prof[kernel];
+    if (k.pending.size() >= kMaxPending || k.open) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    k.open = e;
+}
+void gsr_profile_end(int kernel, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    KernelProf& k = g_prof[kernel];
+    if (!k.open) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipEventDestroy(k.open); k.open = nullptr; return; }
+    (void)hipEventRecord(e, s);
+    k.pending.emplace_back(k.open, e);
+    k.open = nullptr;
+}
+extern "C" void gsr_profile_enable(int32_t on) { g_prof_on = on != 0; }
+extern "C" void gsr_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& k : g_prof) { prof_drain(k); k.total_ms = 0.0; k.launches = 0; }
+}
+extern "C" int32_t gsr_profile_read(const char* kernel, double* total_ms, int32_t* launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < GSR_K_COUNT; ++i) {
+        if (strcmp(kernel, g_kernel_names[i]) == 0) {
+            prof_drain(g_prof[i]);
+            if (total_ms) *total_ms = g_prof[i].total_ms;
+            if (launches) *launches = g_prof[i].launches;
+            return GSR_OK;
+        }
+    }
+    gsr_set_error("unknown kernel name '%s'", kernel);
+    return GSR_E_INVALID;
+}
+
+// ------------------------------------------------------------------------------- helpers
+static int validate(const GsrView* v, const GsrGaussians* g) {
+    if (!v || !g) { gsr_set_error("null view / gaussians"); return GSR_E_INVALID; }
+    if (v->width <= 0 || v->height <= 0) { gsr_set_error("bad image size %dx%d", v->width, v->height); return GSR_E_INVALID; }
+    if (g->count < 0) { gsr_set_error("negative Gaussian count"); return GSR_E_INVALID; }
+    if (v->channels != 3) { gsr_set_error("channels=%d: only 3 colour channels are supported", v->channels); return GSR_E_UNSUPPORTED; }
+    if ((g->shs == nullptr) == (g->colors_precomp == nullptr)) {
+        gsr_set_error("Please provide excatly one of either SHs or precomputed colors!");
+        return GSR_E_INVALID;
+    }
+    const bool sr = g->scales != nullptr && g->rotations != nullptr;
+    const bool any_sr = g->scales != nullptr || g->rotations != nullptr;
+    if ((!sr && g->transmat_precomp == nullptr) || (any_sr && g->transmat_precomp != nullptr)) {
+        gsr_set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+        return GSR_E_INVALID;
+    }
+    if (g->shs) {
+        if (v->sh_degree < 0 || v->sh_degree > 3) { gsr_set_error("sh_degree %d not in 0..3", v->sh_degree); return GSR_E_UNSUPPORTED; }
+        if (v->sh_coeffs < (v->sh_degree + 1) * (v->sh_degree + 1)) {
+            gsr_set_error("sh_coeffs=%d too small for degree %d", v->sh_coeffs, v->sh_degree);
+            return GSR_E_INVALID;
+        }
+    }
+    if (g->count > 0 && (!g->means3D || !g->opacities)) { gsr_set_error("means3D / opacities missing"); return GSR_E_INVALID; }
+    if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos) { gsr_set_error("view pointers missing"); return GSR_E_INVALID; }
+    return GSR_OK;
+}
+
+static inline int bits_for(uint32_t n_values) {   // bits needed to represent 0..n_values-1
+    int b = 0;
+    while ((1ull << b) < n_values) ++b;
+    return b;
+}
+
+template <typename T>
+static inline T* at(void* base, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
+template <typename T>
+static inline const T* at(const void* base, size_t off) { return reinterpret_cast<const T*>(static_cast<const char*>(base) + off); }
+
+// ------------------------------------------------------------------------------- forward
+extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrForwardOut* out,
+                               gsr_alloc_fn alloc, void* ctx, gsr_stream_t stream_) {
+    int rc = validate(view, g);
+    if (rc != GSR_OK) return rc;
+    if (!out || !alloc || !out->out_color || !out->out_allmap || (g->count > 0 && !out->radii)) {
+        gsr_set_error("forward outputs / allocator missing");
+        return GSR_E_INVALID;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const int N = g->count, W = view->width, H = view->height;
+    const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+    const int n_tiles = gx * gy;
+    const int64_t P = (int64_t)W * H;
+
+    const GsrGeomLayout GL(N);
+    const GsrImageLayout IL(P);
+    void* geom = alloc(ctx, GSR_BUF_GEOM, GL.total);
+    void* image = alloc(ctx, GSR_BUF_IMAGE, IL.total);
+    if (!geom || !image) { gsr_set_error("allocator returned NULL (geom/image)"); return GSR_E_ALLOC; }
+    out->geom = geom; out->image = image; out->binning = nullptr; out->num_rendered = 0;
+
+    float* splat = at<float>(geom, GL.splat);
+    uint32_t* clamped = at<uint32_t>(geom, GL.clamped);
+    uint32_t* tiles_touched = at<uint32_t>(geom, GL.tiles_touched);
+    uint32_t* inst_begin = at<uint32_t>(geom, GL.inst_begin);
+    uint32_t* depth_key = at<uint32_t>(geom, GL.depth_key);
+
+    // N-sized scratch: depth-sort double buffers, iota, offsets, sort + scan workspaces
+    const size_t nb = gsr_align(size_t(N > 0 ? N : 1) * 4);
+    const size_t sort_ws_n = gsr_sort_ws_bytes(N);
+    const size_t scan_ws_n = gsr_scan_workspace_bytes(N);
+    const size_t scratch_bytes = 4 * nb + gsr_align(size_t(N + 1) * 4) + sort_ws_n + scan_ws_n;
+    char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, scratch_bytes));
+    if (!scratch) { gsr_set_error("allocator returned NULL (scratch)"); return GSR_E_ALLOC; }
+    uint32_t* keys_sorted = reinterpret_cast<uint32_t*>(scratch);
+    uint32_t* order = reinterpret_cast<uint32_t*>(scratch + nb);
+    uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(scratch + 2 * nb);
+    uint32_t* vals_tmp = reinterpret_cast<uint32_t*>(scratch + 3 * nb);
+    uint32_t* offs = reinterpret_cast<uint32_t*>(scratch + 4 * nb);
+    void* sort_ws = scratch + 4 * nb + gsr_align(size_t(N + 1) * 4);
+    void* scan_ws = static_cast<char*>(sort_ws) + sort_ws_n;
+
+    uint32_t D = 0;
+    if (N > 0) {
+        rc = gsr_launch_preprocess_fwd(*view, *g, splat, clamped, tiles_touched, depth_key, out->radii, s);
+        if (rc != GSR_OK) return rc;
+        // depth order of the Gaussians (stable; culled ones carry key 0xFFFFFFFF and no tiles)
+        rc = gsr_radix_sort_pairs(depth_key, nullptr, keys_sorted, order, keys_tmp, vals_tmp, N, 0, 32, sort_ws, s);
+        if (rc != GSR_OK) return rc;
+        rc = gsr_exclusive_scan_u32(tiles_touched, order, offs, N, scan_ws, s);
+        if (rc != GSR_OK) return rc;
+        GSR_HIP_CHECK(hipMemcpyAsync(&D, offs + N, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        GSR_HIP_CHECK(hipStreamSynchronize(s));   // the one permitted sync: D sizes the next buffers
+    }
+    if (D > 0x7FFFFFF0u) { gsr_set_error("instance count %u overflows", D); return GSR_E_UNSUPPORTED; }
+    out->num_rendered = (int32_t)D;
+
+    const GsrBinLayout BL(D, n_tiles);
+    void* binning = alloc(ctx, GSR_BUF_BINNING, BL.total);
+    if (!binning) { gsr_set_error("allocator returned NULL (binning)"); return GSR_E_ALLOC; }
+    out->binning = binning;
+    uint32_t* point_list = at<uint32_t>(binning, BL.point_list);
+    uint32_t* inst_row = at<uint32_t>(binning, BL.inst_row);
+    uint32_t* ranges = at<uint32_t>(binning, BL.ranges);
+
+    if (D > 0) {
+        const size_t db = gsr_align(size_t(D) * 4);
+        const size_t sort_ws_d = gsr_sort_ws_bytes(D);
+        char* sc2 = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH2, 7 * db + sort_ws_d));
+        if (!sc2) { gsr_set_error("allocator returned NULL (scratch2)"); return GSR_E_ALLOC; }
+        uint32_t* tile_keys = reinterpret_cast<uint32_t*>(sc2);
+        uint32_t* inst_vals = reinterpret_cast<uint32_t*>(sc2 + db);
+        uint32_t* emit_gid = reinterpret_cast<uint32_t*>(sc2 + 2 * db);
+        uint32_t* tile_sorted = reinterpret_cast<uint32_t*>(sc2 + 3 * db);
+        uint32_t* perm = reinterpret_cast<uint32_t*>(sc2 + 4 * db);
+        uint32_t* tk_tmp = reinterpret_cast<uint32_t*>(sc2 + 5 * db);
+        uint32_t* tv_tmp = reinterpret_cast<uint32_t*>(sc2 + 6 * db);
+        void* sort_ws2 = sc2 + 7 * db;
+        rc = gsr_launch_emit(N, gx, gy, order, offs, splat, out->radii, tiles_touched, inst_begin,
+                             tile_keys, inst_vals, emit_gid, s);
+        if (rc != GSR_OK) return rc;
+        rc = gsr_radix_sort_pairs(tile_keys, inst_vals, tile_sorted, perm, tk_tmp, tv_tmp, D, 0,
+                                  bits_for((uint32_t)n_tiles), sort_ws2, s);
+        if (rc != GSR_OK) return rc;
+        rc = gsr_launch_finalize_bins((int)D, n_tiles, tile_sorted, perm, emit_gid, point_list, inst_row, ranges, s);
+        if (rc != GSR_OK) return rc;
+    } else {
+        GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
+    }
+
+    return gsr_launch_render_fwd(*view, ranges, point_list, splat, at<float>(image, IL.final_T),
+                                 at<uint32_t>(image, IL.n_contrib), out->out_color, out->out_allmap, s);
+}
+
+// ------------------------------------------------------------------------------- backward
+extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int32_t num_rendered,
+                                const int32_t* radii, const void* geom, const void* binning,
+                                const void* image, const float* dL_dcolor, const float* dL_dallmap,
+                                GsrGrads* grads, gsr_alloc_fn alloc, void* ctx, gsr_stream_t stream_) {
+    int rc = validate(view, g);
+    if (rc != GSR_OK) return rc;
+    if (!grads || !alloc || !geom || !binning || !image || !dL_dcolor || !dL_dallmap || num_rendered < 0 ||
+        (g->count > 0 && (!radii || !grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacity)) ||
+        (g->shs && !grads->dL_dshs) || (g->colors_precomp && !grads->dL_dcolors) ||
+        (g->scales && (!grads->dL_dscales || !grads->dL_drotations)) ||
+        (g->transmat_precomp && !grads->dL_dtransmat)) {
+        gsr_set_error("backward inputs / gradient outputs missing");
+        return GSR_E_INVALID;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const int N = g->count, W = view->width, H = view->height;
+    const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+    const GsrGeomLayout GL(N);
+    const GsrBinLayout BL(num_rendered, gx * gy);
+    const GsrImageLayout IL((int64_t)W * H);
+
+    const size_t rows_bytes = gsr_align(size_t(num_rendered > 0 ? num_rendered : 1) * GSR_GROW_FLOATS * 4);
+    float* grad_rows = static_cast<float*>(alloc(ctx, GSR_BUF_SCRATCH, rows_bytes));
+    if (!grad_rows) { gsr_set_error("allocator returned NULL (gradient rows)"); return GSR_E_ALLOC; }
+
+    if (num_rendered > 0) {
+        rc = gsr_launch_render_bwd(*view, at<uint32_t>(binning, BL.ranges), at<uint32_t>(binning, BL.point_list),
+                                   at<uint32_t>(binning, BL.inst_row), at<float>(geom, GL.splat),
+                                   at<float>(image, IL.final_T), at<uint32_t>(image, IL.n_contrib),
+                                   dL_dcolor, dL_dallmap, grad_rows, s);
+        if (rc != GSR_OK) return rc;
+    }
+    GsrGrads o = *grads;
+    if (!g->shs) o.dL_dshs = nullptr;
+    if (!g->colors_precomp) o.dL_dcolors = nullptr;
+    if (!g->scales) { o.dL_dscales = nullptr; o.dL_drotations = nullptr; }
+    if (!g->transmat_precomp) o.dL_dtransmat = nullptr;
+    return gsr_launch_preprocess_bwd(*view, *g, radii, at<float>(geom, GL.splat), at<uint32_t>(geom, GL.clamped),
+                                     at<uint32_t>(geom, GL.tiles_touched), at<uint32_t>(geom, GL.inst_begin),
+                                     grad_rows, o, s);
+}
+
+// ------------------------------------------------------------------------------- introspection
+extern "C" int32_t gsr_buffer_field(int32_t which, const char* name, int32_t N, int32_t D, int32_t W,
+                                    int32_t H, size_t* offset, size_t* bytes) {
+    if (!name || !offset || !bytes) { gsr_set_error("null argument"); return GSR_E_INVALID; }
+    const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+    const int64_t P = (int64_t)W * H;
+    if (which == GSR_BUF_GEOM) {
+        const GsrGeomLayout L(N);
+        if (!strcmp(name, "splat")) { *offset = L.splat; *bytes = size_t(N) * GSR_SPLAT_FLOATS * 4; return GSR_OK; }
+        if (!strcmp(name, "clamped")) { *offset = L.clamped; *bytes = size_t(N) * 4; return GSR_OK; }
+        if (!strcmp(name, "tiles_touched")) { *offset = L.tiles_touched; *bytes = size_t(N) * 4; return GSR_OK; }
+        if (!strcmp(name, "inst_begin")) { *offset = L.inst_begin; *bytes = size_t(N) * 4; return GSR_OK; }
+        if (!strcmp(name, "depth_key")) { *offset = L.depth_key; *bytes = size_t(N) * 4; return GSR_OK; }
+    } else if (which == GSR_BUF_BINNING) {
+        const GsrBinLayout L(D, gx * gy);
+        if (!strcmp(name, "point_list")) { *offset = L.point_list; *bytes = size_t(D) * 4; return GSR_OK; }
+        if (!strcmp(name, "inst_row")) { *offset = L.inst_row; *bytes = size_t(D) * 4; return GSR_OK; }
+        if (!strcmp(name, "ranges")) { *offset = L.ranges; *bytes = size_t(gx) * gy * 8; return GSR_OK; }
+    } else if (which == GSR_BUF_IMAGE) {
+        const GsrImageLayout L(P);
+        if (!strcmp(name, "final_T")) { *offset = L.final_T; *bytes = size_t(P) * 12; return GSR_OK; }
+        if (!strcmp(name, "n_contrib")) { *offset = L.n_contrib; *bytes = size_t(P) * 8; return GSR_OK; }
+    }
+    gsr_set_error("unknown buffer field %d/'%s'", which, name);
+    return GSR_E_INVALID;
+}
+
+// ------------------------------------------------------------------------------- sort entry point
+extern "C" size_t gsr_sort_workspace_bytes(int32_t n) {
+    return 2 * gsr_align(size_t(n > 0 ? n : 1) * 4) + gsr_sort_ws_bytes(n);
+}
+extern "C" int32_t gsr_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+                                      uint32_t* vals_out, int32_t n, int32_t begin_bit, int32_t end_bit,
+                                      void* ws, size_t ws_bytes, gsr_stream_t stream) {
+    if (n < 0 || begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) { gsr_set_error("bad sort arguments"); return GSR_E_INVALID; }
+    if (n == 0) return GSR_OK;
+    if (!keys_in || !keys_out || !vals_out || !ws || ws_bytes < gsr_sort_workspace_bytes(n)) {
+        gsr_set_error("sort buffers / workspace too small");
+        return GSR_E_INVALID;
+    }
+    const size_t nb = gsr_align(size_t(n) * 4);
+    char* w = static_cast<char*>(ws);
+    return gsr_radix_sort_pairs(keys_in, vals_in, keys_out, vals_out, reinterpret_cast<uint32_t*>(w),
+                                reinterpret_cast<uint32_t*>(w + nb), n, begin_bit, end_bit, w + 2 * nb,
+                                static_cast<hipStream_t>(stream));
+}

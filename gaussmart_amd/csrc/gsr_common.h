@@ -1,0 +1,139 @@
+// Internal declarations shared by the kernels and the host orchestration of libgsr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gsr.h"
+#include "gsr_constants.h"
+
+// ---------------------------------------------------------------- error plumbing
+void gsr_set_error(const char* fmt, ...);
+#define GSR_HIP_CHECK(expr)                                                         \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            gsr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                          __FILE__, __LINE__);                                      \
+            return GSR_E_HIP;                                                       \
+        }                                                                           \
+    } while (0)
+#define GSR_LAUNCH_CHECK() GSR_HIP_CHECK(hipGetLastError())
+
+// ---------------------------------------------------------------- profiler hooks
+enum GsrKernelId {
+    GSR_K_PREPROCESS_FWD = 0, GSR_K_SORT_HIST, GSR_K_SORT_SCATTER, GSR_K_SCAN, GSR_K_EMIT,
+    GSR_K_FINALIZE, GSR_K_RENDER_FWD, GSR_K_RENDER_BWD, GSR_K_PREPROCESS_BWD, GSR_K_KNN,
+    GSR_K_COUNT
+};
+bool gsr_profile_on();
+void gsr_profile_begin(int kernel, hipStream_t s);
+void gsr_profile_end(int kernel, hipStream_t s);
+struct GsrProfileScope {
+    int k; hipStream_t s; bool on;
+    GsrProfileScope(int k_, hipStream_t s_) : k(k_), s(s_), on(gsr_profile_on()) { if (on) gsr_profile_begin(k, s); }
+    ~GsrProfileScope() { if (on) gsr_profile_end(k, s); }
+};
+
+// ---------------------------------------------------------------- buffer layouts
+// One "splat record" per Gaussian, written by preprocess_fwd and gathered by the render kernels
+// in 16-byte pieces: [Tu.xyz Tv.xyz Tw.xyz | xy | n.xyz opa | rgb | depth pad]
+#define GSR_SPLAT_FLOATS 20
+#define GSR_SP_TU 0
+#define GSR_SP_TV 3
+#define GSR_SP_TW 6
+#define GSR_SP_XY 9
+#define GSR_SP_NRM 11
+#define GSR_SP_OPA 14
+#define GSR_SP_RGB 15
+#define GSR_SP_DEPTH 18
+
+// One gradient row per (Gaussian, tile) instance, written by render_bwd, summed by
+// preprocess_bwd: [dTu.xyz dTv.xyz dTw.xyz | dxy | dn.xyz | dopa | drgb | pad pad]
+#define GSR_GROW_FLOATS 20
+#define GSR_GR_T 0
+#define GSR_GR_XY 9
+#define GSR_GR_NRM 11
+#define GSR_GR_OPA 14
+#define GSR_GR_RGB 15
+
+static inline size_t gsr_align(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct GsrGeomLayout {
+    size_t splat, clamped, tiles_touched, inst_begin, depth_key, total;
+    explicit GsrGeomLayout(int64_t N) {
+        size_t o = 0;
+        splat = o;         o += gsr_align(size_t(N) * GSR_SPLAT_FLOATS * 4);
+        clamped = o;       o += gsr_align(size_t(N) * 4);
+        tiles_touched = o; o += gsr_align(size_t(N) * 4);
+        inst_begin = o;    o += gsr_align(size_t(N) * 4);
+        depth_key = o;     o += gsr_align(size_t(N) * 4);
+        total = o > 0 ? o : 256;
+    }
+};
+struct GsrBinLayout {
+    size_t point_list, inst_row, ranges, total;
+    GsrBinLayout(int64_t D, int64_t tiles) {
+        size_t o = 0;
+        point_list = o; o += gsr_align(size_t(D) * 4);
+        inst_row = o;   o += gsr_align(size_t(D) * 4);
+        ranges = o;     o += gsr_align(size_t(tiles) * 8);
+        total = o > 0 ? o : 256;
+    }
+};
+struct GsrImageLayout {
+    size_t final_T, n_contrib, total;
+    explicit GsrImageLayout(int64_t P) {
+        size_t o = 0;
+        final_T = o;   o += gsr_align(size_t(P) * 3 * 4);
+        n_contrib = o; o += gsr_align(size_t(P) * 2 * 4);
+        total = o > 0 ? o : 256;
+    }
+};
+
+// ---------------------------------------------------------------- device primitives (binning.hip)
+size_t gsr_scan_workspace_bytes(int64_t n);
+// exclusive scan of n u32 values; out[n] receives the total (out has n+1 entries).
+// `gather` (may be NULL): in[i] is read as in[gather[i]].
+int gsr_exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
+                           void* ws, hipStream_t s);
+size_t gsr_sort_ws_bytes(int64_t n);
+int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+                         uint32_t* vals_out, uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n,
+                         int begin_bit, int end_bit, void* ws, hipStream_t s);
+
+// ---------------------------------------------------------------- kernel launchers
+int gsr_launch_preprocess_fwd(const GsrView& v, const GsrGaussians& g, float* splat,
+                              uint32_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key,
+                              int32_t* radii, hipStream_t s);
+int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const uint32_t* offs,
+                    const float* splat, const int32_t* radii, const uint32_t* tiles_touched,
+                    uint32_t* inst_begin, uint32_t* tile_keys, uint32_t* inst_vals,
+                    uint32_t* emit_gid, hipStream_t s);
+int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted,
+                             const uint32_t* perm, const uint32_t* emit_gid, uint32_t* point_list,
+                             uint32_t* inst_row, uint32_t* ranges, hipStream_t s);
+int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const uint32_t* point_list,
+                          const float* splat, float* final_T, uint32_t* n_contrib,
+                          float* out_color, float* out_allmap, hipStream_t s);
+int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* point_list,
+                          const uint32_t* inst_row, const float* splat, const float* final_T,
+                          const uint32_t* n_contrib, const float* dL_dcolor,
+                          const float* dL_dallmap, float* grad_rows, hipStream_t s);
+int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int32_t* radii,
+                              const float* splat, const uint32_t* clamped,
+                              const uint32_t* tiles_touched, const uint32_t* inst_begin,
+                              const float* grad_rows, const GsrGrads& out, hipStream_t s);
+
+// ---------------------------------------------------------------- small device helpers
+#ifdef __HIPCC__
+// v_rcp_f32 (1 ulp); the parity budget is 1e-4 relative
+__device__ __forceinline__ float gsr_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ void gsr_tile_rect(float cx, float cy, int radius, int gx, int gy,
+                                              int& x0, int& y0, int& x1, int& y1) {
+    // (int) casts truncate toward zero exactly like the recalled getRect
+    x0 = min(gx, max(0, (int)((cx - radius) / GSR_TILE)));
+    y0 = min(gy, max(0, (int)((cy - radius) / GSR_TILE)));
+    x1 = min(gx, max(0, (int)((cx + radius + GSR_TILE - 1) / GSR_TILE)));
+    y1 = min(gy, max(0, (int)((cy + radius + GSR_TILE - 1) / GSR_TILE)));
+}
+#endif

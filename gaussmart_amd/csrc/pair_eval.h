@@ -1,0 +1,50 @@
+// The (pixel, splat) evaluation shared by render_fwd and render_bwd.  Both kernels must take the
+// SAME skip decisions for every pair (the backward replays the forward's traversal), so every
+// multiply-add is an explicit fmaf: no contraction choice is left to the compiler.
+// Math: 2DGS eq. 8-11 (ray-splat intersection through two homogeneous planes, low-pass filter).
+#pragma once
+#include "gsr_common.h"
+
+struct GsrPair {
+    float kx, ky, kz, lx, ly, lz;   // planes k = px*Tw - Tu, l = py*Tw - Tv
+    float inv_pz;                   // 1 / (k x l).z
+    float sx, sy;                   // intersection in splat coordinates
+    float dx, dy;                   // AABB centre - pixel
+    float depth, G, araw, alpha;
+    bool use3d;
+};
+
+// Returns false when the pair is skipped before the transmittance test.
+__device__ __forceinline__ bool gsr_pair_eval(float pxf, float pyf, const float4 a0, const float4 a1,
+                                              const float4 a2, float opa, GsrPair& o) {
+    const float Tux = a0.x, Tuy = a0.y, Tuz = a0.z, Tvx = a0.w, Tvy = a1.x, Tvz = a1.y;
+    const float Twx = a1.z, Twy = a1.w, Twz = a2.x, cx = a2.y, cy = a2.z;
+    o.kx = fmaf(pxf, Twx, -Tux); o.ky = fmaf(pxf, Twy, -Tuy); o.kz = fmaf(pxf, Twz, -Tuz);
+    o.lx = fmaf(pyf, Twx, -Tvx); o.ly = fmaf(pyf, Twy, -Tvy); o.lz = fmaf(pyf, Twz, -Tvz);
+    const float ppx = fmaf(o.ky, o.lz, -(o.kz * o.ly));
+    const float ppy = fmaf(o.kz, o.lx, -(o.kx * o.lz));
+    const float ppz = fmaf(o.kx, o.ly, -(o.ky * o.lx));
+    if (ppz == 0.0f) return false;
+    o.inv_pz = gsr_rcp(ppz);
+    o.sx = ppx * o.inv_pz; o.sy = ppy * o.inv_pz;
+    const float rho3d = fmaf(o.sx, o.sx, o.sy * o.sy);
+    o.dx = cx - pxf; o.dy = cy - pyf;
+    const float rho2d = GSR_FILTER_INV_SQUARE * fmaf(o.dx, o.dx, o.dy * o.dy);
+    o.use3d = rho3d <= rho2d;
+    const float rho = fminf(rho3d, rho2d);
+    o.depth = o.use3d ? fmaf(o.sx, Twx, fmaf(o.sy, Twy, Twz)) : Twz;
+    if (o.depth < GSR_NEAR_N) return false;
+    const float power = -0.5f * rho;
+    if (power > 0.0f) return false;
+    o.G = __expf(power);
+    o.araw = opa * o.G;
+    o.alpha = fminf(GSR_ALPHA_MAX, o.araw);
+    return o.alpha >= GSR_ALPHA_MIN;
+}
+
+// distortion depth mapping m(z) and its derivative
+__device__ __forceinline__ float gsr_depth_map(float z, float& dm_dz) {
+    const float iz = gsr_rcp(z);
+    dm_dz = (GSR_FAR_N * GSR_NEAR_N) / (GSR_FAR_N - GSR_NEAR_N) * iz * iz;
+    return GSR_FAR_N / (GSR_FAR_N - GSR_NEAR_N) * (1.0f - GSR_NEAR_N * iz);
+}

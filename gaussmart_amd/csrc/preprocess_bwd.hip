@@ -1,0 +1,313 @@
+// K8 preprocess_bwd: one thread per Gaussian.
+//   1. sum this Gaussian's per-instance gradient rows (contiguous: rows are in emission order),
+//   2. densification statistic for means2D.grad (consumer scene/gaussian_model.py:551-553),
+//   3. chain rule  AABB centre -> T,  T -> (mean3D, scale, quaternion),  normal -> quaternion,
+//   4. SH backward (clamp mask, view-direction term into mean3D).
+// Restates the [U] preprocess backward; differentiates preprocess_fwd.hip exactly (same anchors).
+// HBM-bound: reads 80 B x instances + 232 B, writes 232 B (192 of them dSH) per Gaussian; the SH
+// block is staged through LDS both ways so global traffic is coalesced 16-byte accesses.
+#include "gsr_common.h"
+
+#define PB_BLOCK 256
+#define SH_ROW_FLOATS 52
+
+struct PreBwdParams {
+    int N, W, H;
+    int deg, M;
+    float mod;
+    const float* view; const float* proj; const float* campos;
+    const float* means; const float* shs; const float* scales; const float* rots;
+    const float* tprecomp;
+    const int32_t* radii; const float* splat; const uint32_t* clamped;
+    const uint32_t* tiles; const uint32_t* inst_begin; const float* grad_rows;
+    GsrGrads out;
+};
+
+template <bool STAGE_SH>
+__global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int idx = blockIdx.x * PB_BLOCK + tid;
+    const int wave_first = blockIdx.x * PB_BLOCK + wave * 64;
+    const int row_f = p.M * 3;
+    const int n_here = min(64, p.N - wave_first);
+    const bool has_sh = p.shs != nullptr;
+
+    float* wl = lds + wave * 64 * SH_ROW_FLOATS;
+    float* my_sh = wl + lane * SH_ROW_FLOATS;
+    if (STAGE_SH && n_here > 0) {
+        const float4* src = reinterpret_cast<const float4*>(p.shs + (size_t)wave_first * row_f);
+        const int vec_per_row = row_f >> 2;
+        const int total_vec = n_here * vec_per_row;
+        for (int v = lane; v < total_vec; v += 64) {
+            const float4 d = src[v];
+            const int row = v / vec_per_row, col = (v - row * vec_per_row) << 2;
+            *reinterpret_cast<float4*>(wl + row * SH_ROW_FLOATS + col) = d;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    const bool valid = idx < p.N;
+    const bool visible = valid && p.radii[idx] > 0;
+
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dT[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dxy0 = 0.f, dxy1 = 0.f, dn[3] = {0.f, 0.f, 0.f}, dopa = 0.f, drgb[3] = {0.f, 0.f, 0.f};
+    float d2d0 = 0.f, d2d1 = 0.f;
+    float dscale0 = 0.f, dscale1 = 0.f, dq[4] = {0.f, 0.f, 0.f, 0.f};
+
+    float Tu[3], Tv[3], Tw[3];
+    if (visible) {
+        // ---- 1. instance rows ---------------------------------------------------------------
+        const uint32_t b = p.inst_begin[idx], cnt = p.tiles[idx];
+        float acc[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) acc[k] = 0.f;
+        const float4* rows = reinterpret_cast<const float4*>(p.grad_rows + (size_t)b * GSR_GROW_FLOATS);
+        for (uint32_t e = 0; e < cnt; ++e) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const float4 v = rows[(size_t)e * 5 + q];
+                acc[4 * q + 0] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dT[k] = acc[GSR_GR_T + k];
+        dxy0 = acc[GSR_GR_XY]; dxy1 = acc[GSR_GR_XY + 1];
+        dn[0] = acc[GSR_GR_NRM]; dn[1] = acc[GSR_GR_NRM + 1]; dn[2] = acc[GSR_GR_NRM + 2];
+        dopa = acc[GSR_GR_OPA];
+        drgb[0] = acc[GSR_GR_RGB]; drgb[1] = acc[GSR_GR_RGB + 1]; drgb[2] = acc[GSR_GR_RGB + 2];
+
+        const float* rec = p.splat + (size_t)idx * GSR_SPLAT_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { Tu[i] = rec[GSR_SP_TU + i]; Tv[i] = rec[GSR_SP_TV + i]; Tw[i] = rec[GSR_SP_TW + i]; }
+
+        // ---- 2. densification statistic from the RAW dL/dT ---------------------------------
+        d2d0 = dT[2] * Tw[2] * 0.5f * (float)p.W;
+        d2d1 = dT[5] * Tw[2] * 0.5f * (float)p.H;
+
+        // ---- 3a. AABB centre -> T -----------------------------------------------------------
+        if (dxy0 != 0.f || dxy1 != 0.f) {
+            const float t[3] = {GSR_CUTOFF * GSR_CUTOFF, GSR_CUTOFF * GSR_CUTOFF, -1.0f};
+            const float d = t[0] * Tw[0] * Tw[0] + t[1] * Tw[1] * Tw[1] + t[2] * Tw[2] * Tw[2];
+            const float inv_d = 1.0f / d;
+            float dL_dd = 0.f;
+            float dTw_add[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float f = t[i] * inv_d;
+                dT[0 + i] += dxy0 * f * Tw[i];
+                dT[3 + i] += dxy1 * f * Tw[i];
+                dTw_add[i] = dxy0 * f * Tu[i] + dxy1 * f * Tv[i];
+                const float dL_df = dxy0 * Tu[i] * Tw[i] + dxy1 * Tv[i] * Tw[i];
+                dL_dd += dL_df * f;
+            }
+            dL_dd *= -inv_d;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dT[6 + i] += dTw_add[i] + dL_dd * t[i] * Tw[i] * 2.0f;
+        }
+
+        if (p.tprecomp == nullptr) {
+            // ---- 3b. T -> rows of H = [tu,0; tv,0; p,1] ------------------------------------
+            const float* P = p.proj;
+            const float hw = 0.5f * (float)p.W, hh = 0.5f * (float)p.H;
+            const float cw = 0.5f * (float)(p.W - 1), ch = 0.5f * (float)(p.H - 1);
+            float dtu[3], dtv[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                // M3[r][c]: column c in (x, y, w) of projmatrix @ ndc2pix
+                const float m0 = P[4 * r + 0] * hw + P[4 * r + 3] * cw;
+                const float m1 = P[4 * r + 1] * hh + P[4 * r + 3] * ch;
+                const float m2 = P[4 * r + 3];
+                dtu[r] = dT[0] * m0 + dT[3] * m1 + dT[6] * m2;
+                dtv[r] = dT[1] * m0 + dT[4] * m1 + dT[7] * m2;
+                dmean[r] = dT[2] * m0 + dT[5] * m1 + dT[8] * m2;
+            }
+            float qw = p.rots[4 * idx + 0], qx = p.rots[4 * idx + 1], qy = p.rots[4 * idx + 2], qz = p.rots[4 * idx + 3];
+            const float s = rsqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+            qw *= s; qx *= s; qy *= s; qz *= s;
+            const float r00 = 1.f - 2.f * (qy * qy + qz * qz), r10 = 2.f * (qx * qy + qw * qz), r20 = 2.f * (qx * qz - qw * qy);
+            const float r01 = 2.f * (qx * qy - qw * qz), r11 = 1.f - 2.f * (qx * qx + qz * qz), r21 = 2.f * (qy * qz + qw * qx);
+            const float r02 = 2.f * (qx * qz + qw * qy), r12 = 2.f * (qy * qz - qw * qx), r22 = 1.f - 2.f * (qx * qx + qy * qy);
+            const float sx = p.scales[2 * idx + 0] * p.mod, sy = p.scales[2 * idx + 1] * p.mod;
+
+            // normal = sign * (R[:,2] @ V3); the sign is recomputed exactly like the forward
+            const float* V = p.view;
+            const float px = p.means[3 * idx + 0], py = p.means[3 * idx + 1], pz = p.means[3 * idx + 2];
+            const float vx = px * V[0] + py * V[4] + pz * V[8] + V[12];
+            const float vy = px * V[1] + py * V[5] + pz * V[9] + V[13];
+            const float vz = px * V[2] + py * V[6] + pz * V[10] + V[14];
+            const float nv0 = r02 * V[0] + r12 * V[4] + r22 * V[8];
+            const float nv1 = r02 * V[1] + r12 * V[5] + r22 * V[9];
+            const float nv2 = r02 * V[2] + r12 * V[6] + r22 * V[10];
+            const float sgn = (-(vx * nv0 + vy * nv1 + vz * nv2)) > 0.f ? 1.f : -1.f;
+            float dtn[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                dtn[r] = sgn * (dn[0] * V[4 * r + 0] + dn[1] * V[4 * r + 1] + dn[2] * V[4 * r + 2]);
+
+            dscale0 = (dtu[0] * r00 + dtu[1] * r10 + dtu[2] * r20) * p.mod;
+            dscale1 = (dtv[0] * r01 + dtv[1] * r11 + dtv[2] * r21) * p.mod;
+            // dL/dR, column-wise
+            const float d00 = dtu[0] * sx, d10 = dtu[1] * sx, d20 = dtu[2] * sx;
+            const float d01 = dtv[0] * sy, d11 = dtv[1] * sy, d21 = dtv[2] * sy;
+            const float d02 = dtn[0], d12 = dtn[1], d22 = dtn[2];
+            const float gr = 2.f * (-qz * d01 + qy * d02 + qz * d10 - qx * d12 - qy * d20 + qx * d21);
+            const float gx = 2.f * (qy * d01 + qz * d02 + qy * d10 - 2.f * qx * d11 - qw * d12 + qz * d20 + qw * d21 - 2.f * qx * d22);
+            const float gy = 2.f * (-2.f * qy * d00 + qx * d01 + qw * d02 + qx * d10 + qz * d12 - qw * d20 + qz * d21 - 2.f * qy * d22);
+            const float gz = 2.f * (-2.f * qz * d00 - qw * d01 + qx * d02 + qw * d10 - 2.f * qz * d11 + qy * d12 + qx * d20 + qy * d21);
+            dq[0] = gr * s; dq[1] = gx * s; dq[2] = gy * s; dq[3] = gz * s;
+        }
+    }
+
+    // ---- 4. SH backward ---------------------------------------------------------------------
+    if (has_sh) {
+        float basis[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) basis[k] = 0.f;
+        float g[3] = {0.f, 0.f, 0.f};
+        if (visible) {
+            const uint32_t cb = p.clamped[idx];
+            g[0] = (cb & 1u) ? 0.f : drgb[0];
+            g[1] = (cb & 2u) ? 0.f : drgb[1];
+            g[2] = (cb & 4u) ? 0.f : drgb[2];
+            const float ox = p.means[3 * idx + 0] - p.campos[0];
+            const float oy = p.means[3 * idx + 1] - p.campos[1];
+            const float oz = p.means[3 * idx + 2] - p.campos[2];
+            const float il = 1.0f / sqrtf(ox * ox + oy * oy + oz * oz);
+            const float x = ox * il, y = oy * il, z = oz * il;
+            const int deg = p.deg;
+            float dbx[16], dby[16], dbz[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { dbx[k] = 0.f; dby[k] = 0.f; dbz[k] = 0.f; }
+            basis[0] = GSR_SH_C0;
+            if (deg > 0) {
+                basis[1] = -GSR_SH_C1 * y; basis[2] = GSR_SH_C1 * z; basis[3] = -GSR_SH_C1 * x;
+                dby[1] = -GSR_SH_C1; dbz[2] = GSR_SH_C1; dbx[3] = -GSR_SH_C1;
+                if (deg > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    basis[4] = GSR_SH_C2_0 * xy; basis[5] = GSR_SH_C2_1 * yz;
+                    basis[6] = GSR_SH_C2_2 * (2.f * zz - xx - yy);
+                    basis[7] = GSR_SH_C2_3 * xz; basis[8] = GSR_SH_C2_4 * (xx - yy);
+                    dbx[4] = GSR_SH_C2_0 * y; dby[4] = GSR_SH_C2_0 * x;
+                    dby[5] = GSR_SH_C2_1 * z; dbz[5] = GSR_SH_C2_1 * y;
+                    dbx[6] = GSR_SH_C2_2 * -2.f * x; dby[6] = GSR_SH_C2_2 * -2.f * y; dbz[6] = GSR_SH_C2_2 * 4.f * z;
+                    dbx[7] = GSR_SH_C2_3 * z; dbz[7] = GSR_SH_C2_3 * x;
+                    dbx[8] = GSR_SH_C2_4 * 2.f * x; dby[8] = GSR_SH_C2_4 * -2.f * y;
+                    if (deg > 2) {
+                        basis[9] = GSR_SH_C3_0 * y * (3.f * xx - yy);
+                        basis[10] = GSR_SH_C3_1 * xy * z;
+                        basis[11] = GSR_SH_C3_2 * y * (4.f * zz - xx - yy);
+                        basis[12] = GSR_SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                        basis[13] = GSR_SH_C3_4 * x * (4.f * zz - xx - yy);
+                        basis[14] = GSR_SH_C3_5 * z * (xx - yy);
+                        basis[15] = GSR_SH_C3_6 * x * (xx - 3.f * yy);
+                        dbx[9] = GSR_SH_C3_0 * 6.f * xy; dby[9] = GSR_SH_C3_0 * (3.f * xx - 3.f * yy);
+                        dbx[10] = GSR_SH_C3_1 * yz; dby[10] = GSR_SH_C3_1 * xz; dbz[10] = GSR_SH_C3_1 * xy;
+                        dbx[11] = GSR_SH_C3_2 * -2.f * xy; dby[11] = GSR_SH_C3_2 * (4.f * zz - xx - 3.f * yy); dbz[11] = GSR_SH_C3_2 * 8.f * yz;
+                        dbx[12] = GSR_SH_C3_3 * -6.f * xz; dby[12] = GSR_SH_C3_3 * -6.f * yz; dbz[12] = GSR_SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy);
+                        dbx[13] = GSR_SH_C3_4 * (4.f * zz - 3.f * xx - yy); dby[13] = GSR_SH_C3_4 * -2.f * xy; dbz[13] = GSR_SH_C3_4 * 8.f * xz;
+                        dbx[14] = GSR_SH_C3_5 * 2.f * xz; dby[14] = GSR_SH_C3_5 * -2.f * yz; dbz[14] = GSR_SH_C3_5 * (xx - yy);
+                        dbx[15] = GSR_SH_C3_6 * (3.f * xx - 3.f * yy); dby[15] = GSR_SH_C3_6 * -6.f * xy;
+                    }
+                }
+            }
+            // dL/ddir = sum_c g_c * sum_k dbasis_k * sh[k][c]
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+            const int nk = (deg + 1) * (deg + 1);
+            const float* shp = STAGE_SH ? my_sh : p.shs + (size_t)idx * row_f;
+#pragma unroll
+            for (int k = 1; k < 16; ++k) {
+                if (k < nk && k < p.M) {
+                    const float w = g[0] * shp[3 * k] + g[1] * shp[3 * k + 1] + g[2] * shp[3 * k + 2];
+                    ddx += dbx[k] * w; ddy += dby[k] * w; ddz += dbz[k] * w;
+                }
+            }
+            // through the normalisation dir = o / |o|
+            const float dotp = x * ddx + y * ddy + z * ddz;
+            dmean[0] += (ddx - x * dotp) * il;
+            dmean[1] += (ddy - y * dotp) * il;
+            dmean[2] += (ddz - z * dotp) * il;
+        }
+        if (STAGE_SH) {
+            // overwrite the staged coefficients with their gradients, then stream the tile out
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (k < p.M) {
+                        my_sh[3 * k + 0] = basis[k] * g[0];
+                        my_sh[3 * k + 1] = basis[k] * g[1];
+                        my_sh[3 * k + 2] = basis[k] * g[2];
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (n_here > 0) {
+                float4* dst = reinterpret_cast<float4*>(p.out.dL_dshs + (size_t)wave_first * row_f);
+                const int vec_per_row = row_f >> 2;
+                const int total_vec = n_here * vec_per_row;
+                for (int v = lane; v < total_vec; v += 64) {
+                    const int row = v / vec_per_row, col = (v - row * vec_per_row) << 2;
+                    dst[v] = *reinterpret_cast<const float4*>(wl + row * SH_ROW_FLOATS + col);
+                }
+            }
+        } else if (valid) {
+            float* o = p.out.dL_dshs + (size_t)idx * row_f;
+            for (int k = 0; k < p.M; ++k) {
+                const float bk = k < 16 ? basis[k] : 0.f;
+                o[3 * k + 0] = bk * g[0]; o[3 * k + 1] = bk * g[1]; o[3 * k + 2] = bk * g[2];
+            }
+        }
+    }
+
+    if (!valid) return;
+    p.out.dL_dmeans3D[3 * idx + 0] = dmean[0];
+    p.out.dL_dmeans3D[3 * idx + 1] = dmean[1];
+    p.out.dL_dmeans3D[3 * idx + 2] = dmean[2];
+    p.out.dL_dmeans2D[3 * idx + 0] = d2d0;
+    p.out.dL_dmeans2D[3 * idx + 1] = d2d1;
+    p.out.dL_dmeans2D[3 * idx + 2] = 0.f;
+    p.out.dL_dopacity[idx] = dopa;
+    if (p.out.dL_dcolors) {
+        p.out.dL_dcolors[3 * idx + 0] = drgb[0]; p.out.dL_dcolors[3 * idx + 1] = drgb[1]; p.out.dL_dcolors[3 * idx + 2] = drgb[2];
+    }
+    if (p.out.dL_dscales) { p.out.dL_dscales[2 * idx + 0] = dscale0; p.out.dL_dscales[2 * idx + 1] = dscale1; }
+    if (p.out.dL_drotations) {
+        p.out.dL_drotations[4 * idx + 0] = dq[0]; p.out.dL_drotations[4 * idx + 1] = dq[1];
+        p.out.dL_drotations[4 * idx + 2] = dq[2]; p.out.dL_drotations[4 * idx + 3] = dq[3];
+    }
+    if (p.out.dL_dtransmat) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) p.out.dL_dtransmat[9 * (size_t)idx + k] = dT[k];
+    }
+}
+
+int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int32_t* radii,
+                              const float* splat, const uint32_t* clamped,
+                              const uint32_t* tiles_touched, const uint32_t* inst_begin,
+                              const float* grad_rows, const GsrGrads& out, hipStream_t s) {
+    if (g.count <= 0) return GSR_OK;
+    PreBwdParams p;
+    p.N = g.count; p.W = v.width; p.H = v.height; p.deg = v.sh_degree; p.M = v.sh_coeffs;
+    p.mod = v.scale_modifier; p.view = v.viewmatrix; p.proj = v.projmatrix; p.campos = v.campos;
+    p.means = g.means3D; p.shs = g.shs; p.scales = g.scales; p.rots = g.rotations;
+    p.tprecomp = g.transmat_precomp; p.radii = radii; p.splat = splat; p.clamped = clamped;
+    p.tiles = tiles_touched; p.inst_begin = inst_begin; p.grad_rows = grad_rows; p.out = out;
+    const int blocks = (g.count + PB_BLOCK - 1) / PB_BLOCK;
+    GsrProfileScope prof(GSR_K_PREPROCESS_BWD, s);
+    const bool stage = g.shs != nullptr && v.sh_coeffs * 3 <= 48 && (v.sh_coeffs * 3) % 4 == 0 &&
+                       (reinterpret_cast<uintptr_t>(g.shs) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(out.dL_dshs) & 15) == 0;
+    if (stage) {
+        const size_t lds_bytes = (size_t)(PB_BLOCK / 64) * 64 * SH_ROW_FLOATS * sizeof(float);
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(PB_BLOCK), lds_bytes, s, p);
+    } else {
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(PB_BLOCK), 0, s, p);
+    }
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}

@@ -1,0 +1,216 @@
+// K1 preprocess_fwd: one thread per Gaussian.
+//   view cull -> quat -> T (splat->pixel homography, rows Tu,Tv,Tw) -> AABB radius + tile rect
+//   -> view-space normal -> SH colour (+clamp mask) -> 80-byte splat record.
+// Restates the [U] preprocess of the un-vendored rasterizer; in-tree anchors:
+//   T matrix / (W-1)/2 convention   gaussian_renderer/__init__.py:64-75
+//   quaternion -> R                 utils/general_utils.py:78-99
+//   SH basis, +0.5, clamp           utils/sh_utils.py:57-112
+// HBM-bound streaming kernel: 232 B read (192 of them SH) + 96 B written per Gaussian.
+// The [N,16,3] SH block of a wave (64 x 192 B = 12 KiB contiguous) is fetched with coalesced
+// 16-byte loads into a wave-private LDS tile with 208-byte rows (conflict-free ds_read_b128 by
+// row) instead of 48 strided dword loads per lane.
+#include "gsr_common.h"
+
+#define PRE_BLOCK 256
+#define SH_ROW_FLOATS 52   // 48 + 4 pad: 16-byte aligned rows, bank-conflict-free b128 reads
+
+struct PreParams {
+    int N, W, H, gx, gy;
+    int deg, M;
+    float mod;
+    const float* view; const float* proj; const float* campos;
+    const float* means; const float* shs; const float* colors; const float* opac;
+    const float* scales; const float* rots; const float* tprecomp;
+    float* splat; uint32_t* clamped; uint32_t* tiles; uint32_t* dkey; int32_t* radii;
+};
+
+__device__ __forceinline__ float3 sh_to_rgb(int deg, const float* sh /*[M][3] in LDS or global*/,
+                                            int stride3, float3 dir, uint32_t& clamp_bits) {
+    // sh[k*stride3 + c]
+    float x = dir.x, y = dir.y, z = dir.z;
+    float r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = GSR_SH_C0 * sh[0 * stride3 + c];
+        if (deg > 0) {
+            v = v - GSR_SH_C1 * y * sh[1 * stride3 + c] + GSR_SH_C1 * z * sh[2 * stride3 + c]
+                  - GSR_SH_C1 * x * sh[3 * stride3 + c];
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                v = v + GSR_SH_C2_0 * xy * sh[4 * stride3 + c] + GSR_SH_C2_1 * yz * sh[5 * stride3 + c]
+                      + GSR_SH_C2_2 * (2.0f * zz - xx - yy) * sh[6 * stride3 + c]
+                      + GSR_SH_C2_3 * xz * sh[7 * stride3 + c]
+                      + GSR_SH_C2_4 * (xx - yy) * sh[8 * stride3 + c];
+                if (deg > 2) {
+                    v = v + GSR_SH_C3_0 * y * (3.0f * xx - yy) * sh[9 * stride3 + c]
+                          + GSR_SH_C3_1 * xy * z * sh[10 * stride3 + c]
+                          + GSR_SH_C3_2 * y * (4.0f * zz - xx - yy) * sh[11 * stride3 + c]
+                          + GSR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[12 * stride3 + c]
+                          + GSR_SH_C3_4 * x * (4.0f * zz - xx - yy) * sh[13 * stride3 + c]
+                          + GSR_SH_C3_5 * z * (xx - yy) * sh[14 * stride3 + c]
+                          + GSR_SH_C3_6 * x * (xx - 3.0f * yy) * sh[15 * stride3 + c];
+                }
+            }
+        }
+        v += 0.5f;
+        if (v < 0.0f) clamp_bits |= (1u << c);
+        r[c] = fmaxf(v, 0.0f);
+    }
+    return make_float3(r[0], r[1], r[2]);
+}
+
+template <bool STAGE_SH>
+__global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int idx = blockIdx.x * PRE_BLOCK + tid;
+    const int wave_first = blockIdx.x * PRE_BLOCK + wave * 64;
+
+    float* my_sh = nullptr;
+    if (STAGE_SH) {
+        // cooperative, fully coalesced fetch of this wave's 64 x (M*3) floats; M*3 % 4 == 0 here
+        float* wl = lds + wave * 64 * SH_ROW_FLOATS;
+        const int row_f = p.M * 3;                 // 48 for degree-3 storage
+        const int n_here = min(64, p.N - wave_first);
+        if (n_here > 0) {
+            const float4* src = reinterpret_cast<const float4*>(p.shs + (size_t)wave_first * row_f);
+            const int vec_per_row = row_f >> 2;
+            const int total_vec = n_here * vec_per_row;
+            for (int v = lane; v < total_vec; v += 64) {
+                float4 d = src[v];
+                int row = v / vec_per_row, col = (v - row * vec_per_row) << 2;
+                *reinterpret_cast<float4*>(wl + row * SH_ROW_FLOATS + col) = d;
+            }
+        }
+        my_sh = wl + lane * SH_ROW_FLOATS;
+        // wave-private region: LDS ops of one wave complete in order, no workgroup barrier needed
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (idx >= p.N) return;
+
+    // defaults for a culled Gaussian
+    p.radii[idx] = 0;
+    p.tiles[idx] = 0;
+    p.dkey[idx] = 0xFFFFFFFFu;
+
+    const float* V = p.view;
+    const float* P = p.proj;
+    const float px = p.means[3 * idx + 0], py = p.means[3 * idx + 1], pz = p.means[3 * idx + 2];
+    const float vx = px * V[0] + py * V[4] + pz * V[8] + V[12];
+    const float vy = px * V[1] + py * V[5] + pz * V[9] + V[13];
+    const float vz = px * V[2] + py * V[6] + pz * V[10] + V[14];
+    if (!(vz > GSR_NEAR_N)) return;
+
+    float Tu[3], Tv[3], Tw[3], nrm[3];
+    if (p.tprecomp == nullptr) {
+        float qw = p.rots[4 * idx + 0], qx = p.rots[4 * idx + 1], qy = p.rots[4 * idx + 2],
+              qz = p.rots[4 * idx + 3];
+        const float s = rsqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+        qw *= s; qx *= s; qy *= s; qz *= s;
+        // columns of R (utils/general_utils.py:90-98)
+        const float r00 = 1.f - 2.f * (qy * qy + qz * qz), r10 = 2.f * (qx * qy + qw * qz), r20 = 2.f * (qx * qz - qw * qy);
+        const float r01 = 2.f * (qx * qy - qw * qz), r11 = 1.f - 2.f * (qx * qx + qz * qz), r21 = 2.f * (qy * qz + qw * qx);
+        const float r02 = 2.f * (qx * qz + qw * qy), r12 = 2.f * (qy * qz - qw * qx), r22 = 1.f - 2.f * (qx * qx + qy * qy);
+        const float sx = p.scales[2 * idx + 0] * p.mod, sy = p.scales[2 * idx + 1] * p.mod;
+        const float rows[3][4] = {{r00 * sx, r10 * sx, r20 * sx, 0.f},
+                                  {r01 * sy, r11 * sy, r21 * sy, 0.f},
+                                  {px, py, pz, 1.f}};
+        const float hw = 0.5f * (float)p.W, hh = 0.5f * (float)p.H;
+        const float cw = 0.5f * (float)(p.W - 1), ch = 0.5f * (float)(p.H - 1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float a = rows[i][0], b = rows[i][1], c = rows[i][2], e = rows[i][3];
+            const float h0 = a * P[0] + b * P[4] + c * P[8] + e * P[12];
+            const float h1 = a * P[1] + b * P[5] + c * P[9] + e * P[13];
+            const float h3 = a * P[3] + b * P[7] + c * P[11] + e * P[15];
+            Tu[i] = h0 * hw + h3 * cw;
+            Tv[i] = h1 * hh + h3 * ch;
+            Tw[i] = h3;
+        }
+        nrm[0] = r02 * V[0] + r12 * V[4] + r22 * V[8];
+        nrm[1] = r02 * V[1] + r12 * V[5] + r22 * V[9];
+        nrm[2] = r02 * V[2] + r12 * V[6] + r22 * V[10];
+    } else {
+        const float* t = p.tprecomp + 9 * (size_t)idx;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { Tu[i] = t[i]; Tv[i] = t[3 + i]; Tw[i] = t[6 + i]; }
+        nrm[0] = 0.f; nrm[1] = 0.f; nrm[2] = 1.f;
+    }
+
+    const float cosv = -(vx * nrm[0] + vy * nrm[1] + vz * nrm[2]);
+    if (cosv == 0.0f) return;
+    const float sgn = cosv > 0.0f ? 1.0f : -1.0f;
+    nrm[0] *= sgn; nrm[1] *= sgn; nrm[2] *= sgn;
+
+    // AABB of the 3-sigma ellipse under the homography
+    const float t0 = GSR_CUTOFF * GSR_CUTOFF, t1 = GSR_CUTOFF * GSR_CUTOFF, t2 = -1.0f;
+    const float d = t0 * Tw[0] * Tw[0] + t1 * Tw[1] * Tw[1] + t2 * Tw[2] * Tw[2];
+    if (d == 0.0f) return;
+    const float inv_d = 1.0f / d;
+    const float f0 = t0 * inv_d, f1 = t1 * inv_d, f2 = t2 * inv_d;
+    const float cx = f0 * Tu[0] * Tw[0] + f1 * Tu[1] * Tw[1] + f2 * Tu[2] * Tw[2];
+    const float cy = f0 * Tv[0] * Tw[0] + f1 * Tv[1] * Tw[1] + f2 * Tv[2] * Tw[2];
+    const float h0x = cx * cx - (f0 * Tu[0] * Tu[0] + f1 * Tu[1] * Tu[1] + f2 * Tu[2] * Tu[2]);
+    const float h0y = cy * cy - (f0 * Tv[0] * Tv[0] + f1 * Tv[1] * Tv[1] + f2 * Tv[2] * Tv[2]);
+    const float ex = sqrtf(fmaxf(GSR_AABB_MIN_EXT2, h0x));
+    const float ey = sqrtf(fmaxf(GSR_AABB_MIN_EXT2, h0y));
+    const float radius = ceilf(fmaxf(fmaxf(ex, ey), GSR_CUTOFF * GSR_FILTER_SIZE));
+    if (!(isfinite(cx) && isfinite(cy) && isfinite(radius))) return;
+
+    int x0, y0, x1, y1;
+    gsr_tile_rect(cx, cy, (int)radius, p.gx, p.gy, x0, y0, x1, y1);
+    const int ntiles = (x1 - x0) * (y1 - y0);
+    if (ntiles == 0) return;
+
+    uint32_t clamp_bits = 0;
+    float3 rgb;
+    if (p.colors == nullptr) {
+        float dx = px - p.campos[0], dy = py - p.campos[1], dz = pz - p.campos[2];
+        const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        const float3 dir = make_float3(dx * il, dy * il, dz * il);
+        if (STAGE_SH) rgb = sh_to_rgb(p.deg, my_sh, 3, dir, clamp_bits);
+        else          rgb = sh_to_rgb(p.deg, p.shs + (size_t)idx * p.M * 3, 3, dir, clamp_bits);
+    } else {
+        rgb = make_float3(p.colors[3 * idx], p.colors[3 * idx + 1], p.colors[3 * idx + 2]);
+    }
+
+    float4* rec = reinterpret_cast<float4*>(p.splat + (size_t)idx * GSR_SPLAT_FLOATS);
+    rec[0] = make_float4(Tu[0], Tu[1], Tu[2], Tv[0]);
+    rec[1] = make_float4(Tv[1], Tv[2], Tw[0], Tw[1]);
+    rec[2] = make_float4(Tw[2], cx, cy, nrm[0]);
+    rec[3] = make_float4(nrm[1], nrm[2], p.opac[idx], rgb.x);
+    rec[4] = make_float4(rgb.y, rgb.z, vz, 0.0f);
+    p.clamped[idx] = clamp_bits;
+    p.radii[idx] = (int)radius;
+    p.tiles[idx] = (uint32_t)ntiles;
+    p.dkey[idx] = __float_as_uint(vz);
+}
+
+int gsr_launch_preprocess_fwd(const GsrView& v, const GsrGaussians& g, float* splat,
+                              uint32_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key,
+                              int32_t* radii, hipStream_t s) {
+    if (g.count <= 0) return GSR_OK;
+    PreParams p;
+    p.N = g.count; p.W = v.width; p.H = v.height;
+    p.gx = (v.width + GSR_TILE - 1) / GSR_TILE; p.gy = (v.height + GSR_TILE - 1) / GSR_TILE;
+    p.deg = v.sh_degree; p.M = v.sh_coeffs; p.mod = v.scale_modifier;
+    p.view = v.viewmatrix; p.proj = v.projmatrix; p.campos = v.campos;
+    p.means = g.means3D; p.shs = g.shs; p.colors = g.colors_precomp; p.opac = g.opacities;
+    p.scales = g.scales; p.rots = g.rotations; p.tprecomp = g.transmat_precomp;
+    p.splat = splat; p.clamped = clamped; p.tiles = tiles_touched; p.dkey = depth_key; p.radii = radii;
+    const int blocks = (g.count + PRE_BLOCK - 1) / PRE_BLOCK;
+    GsrProfileScope prof(GSR_K_PREPROCESS_FWD, s);
+    // LDS staging needs whole 16-byte vectors per row and rows that fit the padded tile
+    const bool stage = g.shs != nullptr && v.sh_coeffs * 3 <= 48 && (v.sh_coeffs * 3) % 4 == 0 &&
+                       (reinterpret_cast<uintptr_t>(g.shs) & 15) == 0;
+    if (stage) {
+        const size_t lds_bytes = (size_t)(PRE_BLOCK / 64) * 64 * SH_ROW_FLOATS * sizeof(float);
+        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(blocks), dim3(PRE_BLOCK), lds_bytes, s, p);
+    } else {
+        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(blocks), dim3(PRE_BLOCK), 0, s, p);
+    }
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}

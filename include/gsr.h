@@ -1,0 +1,160 @@
+/*
+ * gsr.h -- C ABI of libgsr_hip.so: MI355X (gfx950) differentiable 2D-Gaussian-surfel rasterizer
+ * and 3-nearest-neighbour mean squared distance.
+ *
+ * What this replaces in alevalve/gaussmart (paths relative to the reference checkout):
+ *   - the native extension `diff_surfel_rasterization._C` (submodules/diff-surfel-rasterization,
+ *     an EMPTY un-pinned submodule: .gitmodules:1-3), reached through
+ *     `GaussianRasterizer(raster_settings)(means3D, means2D, shs, colors_precomp, opacities,
+ *     scales, rotations, cov3D_precomp)`            gaussian_renderer/__init__.py:14,37-53,97-106
+ *   - `simple_knn._C.distCUDA2(points)` (submodules/simple-knn, EMPTY: .gitmodules:4-6)
+ *                                                   scene/gaussian_model.py:22,261
+ * The reference constrains only the Python operator surface; this C layer is what a binding for
+ * that surface calls (see INTEGRATION.md for the ctypes / pybind11 stubs).
+ *
+ * Conventions
+ *   - every pointer marked `device` is HIP device memory owned by the CALLER; the library never
+ *     frees or retains it and keeps no global mutable state besides the opt-in profiler;
+ *   - all work is enqueued on `stream`; gsr_forward performs exactly one stream synchronisation
+ *     (to learn the number of tile instances) before it asks for the instance-sized buffers;
+ *   - matrices are row-major 4x4 in the reference's transposed / row-vector convention
+ *     (viewmatrix = W2C^T, projmatrix = viewmatrix @ P^T; scene/cameras.py:56-58);
+ *   - return value 0 = ok, negative = GSR_E_*; gsr_last_error() gives the thread's last message.
+ */
+#ifndef GSR_H_
+#define GSR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+
+typedef void* gsr_stream_t; /* hipStream_t */
+
+enum {
+    GSR_OK = 0,
+    GSR_E_INVALID = -1,     /* bad argument combination (mirrors the operator's Python checks) */
+    GSR_E_HIP = -2,         /* a HIP runtime call failed                                        */
+    GSR_E_ALLOC = -3,       /* the caller's allocator returned NULL                             */
+    GSR_E_UNSUPPORTED = -4  /* e.g. channels != 3, sh_degree > 3                                */
+};
+
+/* GsrView.flags: reproduce the two places where the recalled upstream backward is not the
+ * derivative of its forward.  GSR_FLAGS_UPSTREAM is what the Python operator passes. */
+enum {
+    GSR_FLAG_CLAMP_PASSTHROUGH = 1, /* gradient flows through alpha = min(0.99, o*G) when clamped */
+    GSR_FLAG_FILTER_DEPTH_GRAD = 2, /* low-pass branch: dL/dz also added to dL/dTw.x,.y times s   */
+    GSR_FLAGS_UPSTREAM = 3
+};
+
+/* GaussianRasterizationSettings (gaussian_renderer/__init__.py:37-51) */
+typedef struct GsrView {
+    int32_t width, height;
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;       /* active degree, 0..3                                  */
+    int32_t sh_coeffs;       /* coefficients stored per Gaussian (shs is [N, M, 3])  */
+    int32_t channels;        /* colour channels, must be 3                           */
+    uint32_t flags;          /* GSR_FLAG_*                                           */
+    const float* bg;         /* device f32[channels]                                 */
+    const float* viewmatrix; /* device f32[16]                                       */
+    const float* projmatrix; /* device f32[16]                                       */
+    const float* campos;     /* device f32[3]                                        */
+} GsrView;
+
+/* Operator inputs (gaussian_renderer/__init__.py:97-106).  Exactly one of shs / colors_precomp
+ * and exactly one of (scales, rotations) / transmat_precomp must be non-NULL. */
+typedef struct GsrGaussians {
+    int32_t count;                 /* N                                              */
+    const float* means3D;          /* device [N,3]                                   */
+    const float* shs;              /* device [N,M,3] or NULL                         */
+    const float* colors_precomp;   /* device [N,3] or NULL                           */
+    const float* opacities;        /* device [N] (post-sigmoid)                      */
+    const float* scales;           /* device [N,2] (post-exp) or NULL                */
+    const float* rotations;        /* device [N,4] (w,x,y,z) or NULL                 */
+    const float* transmat_precomp; /* device [N,9] rows Tu,Tv,Tw, or NULL            */
+} GsrGaussians;
+
+/* Buffers the forward hands to the backward.  The caller allocates them through the callback
+ * (two-phase: the instance-sized ones are requested after the scan) and keeps them alive until
+ * the backward has run.  GSR_BUF_SCRATCH may be released as soon as the call returns
+ * (stream-ordered). */
+enum { GSR_BUF_GEOM = 0, GSR_BUF_BINNING = 1, GSR_BUF_IMAGE = 2, GSR_BUF_SCRATCH = 3,
+       GSR_BUF_SCRATCH2 = 4, GSR_BUF_COUNT = 5 };
+
+/* Must return device memory of >= bytes, 256-byte aligned, or NULL. */
+typedef void* (*gsr_alloc_fn)(void* ctx, int32_t which, size_t bytes);
+
+typedef struct GsrForwardOut {
+    float* out_color;      /* device [3,H,W]                                          */
+    float* out_allmap;     /* device [7,H,W]: depth, alpha, normal xyz (view space), median
+                              depth, distortion (gaussian_renderer/__init__.py:117-141) */
+    int32_t* radii;        /* device [N]                                              */
+    int32_t num_rendered;  /* out: number of (Gaussian, tile) instances D             */
+    void* geom;            /* out: the pointers the allocator returned                */
+    void* binning;
+    void* image;
+} GsrForwardOut;
+
+typedef struct GsrGrads {
+    float* dL_dmeans3D;   /* device [N,3]                                              */
+    float* dL_dmeans2D;   /* device [N,3]: densification statistic, .z = 0
+                             (consumer scene/gaussian_model.py:551-553)                */
+    float* dL_dopacity;   /* device [N]                                                */
+    float* dL_dshs;       /* device [N,M,3] or NULL                                    */
+    float* dL_dcolors;    /* device [N,3] or NULL (when colors_precomp was given)      */
+    float* dL_dscales;    /* device [N,2] or NULL                                      */
+    float* dL_drotations; /* device [N,4] or NULL                                      */
+    float* dL_dtransmat;  /* device [N,9] or NULL (when transmat_precomp was given)    */
+} GsrGrads;
+
+int32_t gsr_abi_version(void);
+const char* gsr_last_error(void);
+
+/* Forward: preprocess -> depth sort -> scan -> instance emit -> tile sort -> ranges -> composite. */
+int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrForwardOut* out,
+                    gsr_alloc_fn alloc, void* alloc_ctx, gsr_stream_t stream);
+
+/* Backward: per-tile back-to-front replay writing one gradient row per instance, then a
+ * per-Gaussian reduction + chain rule.  Every element of every non-NULL GsrGrads array is
+ * written (no pre-zeroing needed).  Deterministic: no floating-point atomics. */
+int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int32_t num_rendered,
+                     const int32_t* radii, const void* geom, const void* binning,
+                     const void* image, const float* dL_dcolor, const float* dL_dallmap,
+                     GsrGrads* grads, gsr_alloc_fn alloc, void* alloc_ctx, gsr_stream_t stream);
+
+/* Introspection of the saved buffers, for parity tests.  Writes byte offset and size of a named
+ * field inside buffer `which` for a problem of N Gaussians, D instances, W x H pixels.
+ * Names: GEOM: "splat" f32[N,20], "clamped" u32[N], "tiles_touched" u32[N], "inst_begin" u32[N],
+ *        "depth_key" u32[N];  BINNING: "point_list" u32[D], "inst_row" u32[D],
+ *        "ranges" u32[tiles,2];  IMAGE: "final_T" f32[3,H,W], "n_contrib" u32[2,H,W]. */
+int32_t gsr_buffer_field(int32_t which, const char* name, int32_t N, int32_t D, int32_t W,
+                         int32_t H, size_t* offset, size_t* bytes);
+
+/* distCUDA2 (scene/gaussian_model.py:261): mean squared distance to the 3 nearest other points. */
+size_t gsr_knn3_workspace_bytes(int32_t n);
+int32_t gsr_knn3(const float* xyz, int32_t n, float* out_mean_sqdist, void* workspace,
+                 size_t workspace_bytes, gsr_stream_t stream);
+
+/* Stable LSD radix sort of (u32 key, u32 value) pairs on bits [begin_bit, end_bit): the sort the
+ * binning uses, exposed so it can be checked bit-exactly at any size. */
+size_t gsr_sort_workspace_bytes(int32_t n);
+int32_t gsr_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+                           uint32_t* vals_out, int32_t n, int32_t begin_bit, int32_t end_bit,
+                           void* workspace, size_t workspace_bytes, gsr_stream_t stream);
+
+/* Opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline figures).
+ * Kernel names: "preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
+ * "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn". */
+void gsr_profile_enable(int32_t on);
+void gsr_profile_reset(void);
+int32_t gsr_profile_read(const char* kernel, double* total_ms, int32_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H_ */
