@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train iters/sec @ 1M Gaussians, 1920x1080 (BASELINE.json `metric`).
+
+One step = one full training iteration of the hot path over one synthetic view:
+  lr update -> render() forward (HIP) -> 0.8*L1 + 0.2*(1-SSIM) + 0.05*normal loss -> backward (HIP)
+  -> [N>1: RCCL all-reduce of the per-Gaussian gradients] -> Adam step.
+Iteration index is fixed in the 7k..30k regime of the reference schedule (train.py:132-133:
+normal loss active, SH degree 3, no densification inside the timed region).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
+kernel (timed live with HIP events on the launch stream) and `cpu_baseline` (the pure-PyTorch
+oracle on a bounded sample of the same frame, on this box's host cores).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU share of this container (cgroup quota / affinity), not the host's core count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
+def algorithmic_bytes(N, D, P):
+    """algorithmic HBM bytes per launch of each big kernel."""
+    return {
+        "preprocess_fwd": N * (232 + 87),
+        "render_fwd": D * 76 + P * 60,
+        "render_bwd": D * (76 + 72) + P * 60,
+        "preprocess_bwd": N * (72 + 232 + 232),
+    }
+
+
+def iteration_bytes(N, D, P, tiles):
+    npass = math.ceil((32 + math.ceil(math.log2(max(tiles, 2)))) / 8)
+    b = algorithmic_bytes(N, D, P)
+    return sum(b.values()) + D * 12 * (1 + 2 * npass) + N * 58 * 28
+
+
+def cpu_baseline(params, cam, n_tiles_sample, n_gauss_sample, dbg, W, H):
+    """Oracle (pure PyTorch, fp32) on the host cores: preprocess on a sample of the Gaussians,
+    forward+backward compositing on a sample of the frame's tiles (the frame's own tile lists),
+    both scaled to the whole frame."""
+    import numpy as np
+    from oracle import surfel_ref as O
+    from gaussmart_amd.synthetic import activate
+    torch.set_num_threads(host_cores())
+    cores = torch.get_num_threads()
+    a = {k: v.cpu() for k, v in activate(params).items()}
+    N = a["means3D"].shape[0]
+    S = O.Settings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.zeros(3), 1.0,
+                   cam.world_view_transform.cpu(), cam.full_proj_transform.cpu(), 3, cam.camera_center.cpu())
+    # (1) per-Gaussian stage, forward + backward through autograd
+    ns = min(n_gauss_sample, N)
+    sub = {k: v[:ns].clone().requires_grad_(True) for k, v in a.items()}
+    t0 = time.perf_counter()
+    geom = O.preprocess(sub["means3D"], sub["scales"], sub["rotations"], sub["opacities"], sub["shs"], None, None, S)
+    (geom.Tm.sum() + geom.xy.sum() + geom.normal.sum() + geom.rgb.sum()).backward()
+    t_pre = (time.perf_counter() - t0) * (N / ns)
+    # (2) compositing, forward + recompute-backward, on evenly spread tiles of the real frame
+    spl = dbg["splat"].cpu()
+    gT, gxy = spl[:, 0:9].reshape(-1, 3, 3).contiguous(), spl[:, 9:11].contiguous()
+    gn, go, gc = spl[:, 11:14].contiguous(), spl[:, 14].contiguous(), spl[:, 15:18].contiguous()
+    plist = dbg["point_list"].cpu().to(torch.int64)
+    ranges = dbg["ranges"].cpu().numpy().astype(np.int64)
+    total_tiles = ranges.shape[0]
+    tiles = [int(i) for i in np.linspace(0, total_tiles - 1, n_tiles_sample).round()]
+    dc, da = torch.ones(3, H, W), torch.ones(7, H, W)
+    t0 = time.perf_counter()
+    out = O.render_tiles(gT, gxy, gn, go, gc, plist, ranges, S, tiles=tiles)
+    O.render_tiles_backward(gT, gxy, gn, go, gc, plist, ranges, out.luse, S, dc, da, tiles=tiles)
+    t_tiles = time.perf_counter() - t0
+    inst_sample = int(sum(ranges[t, 1] - ranges[t, 0] for t in tiles))
+    inst_total = int((ranges[:, 1] - ranges[:, 0]).sum())
+    t_render = t_tiles * (inst_total / max(inst_sample, 1))
+    return {"value": 1.0 / (t_pre + t_render), "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/surfel_ref.py fp32: preprocess fwd+bwd on {ns} of {N} Gaussians ({t_pre:.1f}s scaled) + "
+                      f"composite fwd+bwd on {len(tiles)} of {total_tiles} tiles holding {inst_sample} of {inst_total} "
+                      f"instances ({t_tiles:.1f}s measured, scaled by instances); binning, loss and Adam not included"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tiles", type=int, default=12)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gaussmart_amd import _lib
+    from gaussmart_amd.synthetic import make_scene, perturb, activate, jittered_cameras
+    from gaussmart_amd.gaussian_model import GaussianModel
+    from gaussmart_amd.gaussian_renderer import render
+    from gaussmart_amd.params import OptimizationParams, PipelineParams
+    from gaussmart_amd.trainer import training_step
+    from gaussmart_amd.view_parallel import ViewParallel
+    from gaussmart_amd.rasterizer import rasterize_debug, GaussianRasterizationSettings
+
+    _lib.lib()   # fail loudly if the HIP extension is missing
+    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(dev)}; building scene")
+    N, W, H = args.gaussians, args.width, args.height
+    params, _ = make_scene(N, W, H, seed=0, device="cpu")
+    cam = jittered_cameras(world, W, H, seed=0, device=dev)[rank]   # one view per rank
+    bg = torch.zeros(3, device=dev)
+    pipe, opt = PipelineParams(), OptimizationParams()
+
+    target = GaussianModel(3, device=dev)
+    target.create_from_params(perturb(params))
+    with torch.no_grad():
+        gt = render(cam, target, pipe, bg)["render"].clamp(0, 1).contiguous()
+    del target
+    model = GaussianModel(3, device=dev)
+    model.create_from_params(params)
+    model.training_setup(opt)
+    vp = ViewParallel(model) if world > 1 else None
+
+    base_iter = 10_000
+    def step(i):
+        training_step(model, cam, gt, opt, pipe, bg, base_iter + i, view_parallel=vp)
+
+    log("target rendered; warm-up")
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    log("timing")
+    big = ("preprocess_fwd", "render_fwd", "render_bwd", "preprocess_bwd")
+    _lib.profile_reset()
+    _lib.profile_enable(big)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    prof = _lib.profile_read()
+    log(f"timed {args.steps} steps in {elapsed:.3f}s")
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        # measured instance count of this frame (plugs into the algorithmic byte model)
+        a = activate({k: p.detach() for k, p in zip(("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation"),
+                                                    (model._xyz, model._features_dc, model._features_rest, model._opacity,
+                                                     model._scaling, model._rotation))})
+        rs = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), bg, 1.0,
+                                           cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False)
+        dbg = rasterize_debug(a["means3D"], a["opacities"], a["shs"], None, a["scales"], a["rotations"], None, raster_settings=rs)
+        D, P = dbg["num_rendered"], W * H
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        per_kernel = {k: (ms / n if n else 0.0) for k, (ms, n) in prof.items() if k in big}
+        dom = max(per_kernel, key=per_kernel.get)
+        ab = algorithmic_bytes(N, D, P)
+        achieved = ab[dom] / (per_kernel[dom] * 1e-3) / 1e9 if per_kernel[dom] > 0 else 0.0
+        ms_per_step = elapsed / args.steps * 1e3
+        iter_b = iteration_bytes(N, D, P, tiles)
+        out = {
+            "metric": "train iters/sec @1M Gaussians 1080p", "value": world * args.steps / elapsed, "unit": "iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic {N}-Gaussian {W}x{H} scene (SURVEY 8(d) recipe, seed 0), SH degree 3, "
+                                   f"L1+SSIM+normal loss, Adam; one view per GPU per step",
+                       "gaussians": N, "width": W, "height": H, "instances_D": D,
+                       "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per_kernel[dom]},
+            "kernel_ms": {k: round(v, 4) for k, v in per_kernel.items()},
+            "iteration": {"algorithmic_bytes": iter_b, "hbm_frac": iter_b / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            log(f"GPU part done ({out['value']:.2f} it/s, D={D}); timing the CPU oracle on {host_cores()} cores")
+            out["cpu_baseline"] = cpu_baseline(params, cam, args.cpu_tiles, 100_000, dbg, W, H)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,11 @@ import ctypes as C
 import os
 import threading
 
+# torch ships its own libamdhip64.so.7; it must be the HIP runtime this process uses (device
+# pointers and streams come from torch), so it has to be loaded BEFORE libgsr_hip.so, whose
+# DT_NEEDED entry then binds to the already-loaded SONAME instead of /opt/rocm's copy.
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgsr_hip.so")
 ABI_VERSION = 1
@@ -72,6 +77,9 @@ def lib():
                 f"{LIB_PATH} not found: the HIP extension is not built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C gaussmart_amd/csrc`). "
                 "gaussmart_amd has no CPU fallback.")
+        hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(hip_rt):
+            C.CDLL(hip_rt, mode=C.RTLD_GLOBAL)
         L = C.CDLL(LIB_PATH)
         L.gsr_abi_version.restype = C.c_int32
         L.gsr_last_error.restype = C.c_char_p
@@ -118,8 +126,17 @@ def buffer_field(which: int, name: str, N: int, D: int, W: int, H: int):
     return off.value, nbytes.value
 
 
-def profile_enable(on: bool):
-    lib().gsr_profile_enable(1 if on else 0)
+def profile_enable(kernels=True):
+    """True = all kernels, False = off, or an iterable of kernel names."""
+    if kernels is True:
+        mask = -1
+    elif not kernels:
+        mask = 0
+    else:
+        mask = 0
+        for k in kernels:
+            mask |= 1 << KERNEL_NAMES.index(k)
+    lib().gsr_profile_enable(mask)
 
 
 def profile_reset():

@@ -28,7 +28,7 @@ struct KernelProf {
     int launches = 0;
 };
 std::mutex g_prof_mu;
-bool g_prof_on = false;
+uint32_t g_prof_mask = 0;   // bit k enables timing of kernel id k
 KernelProf g_prof[GSR_K_COUNT];
 const char* const g_kernel_names[GSR_K_COUNT] = {
     "preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
@@ -50,9 +50,10 @@ void prof_drain(KernelProf& k) {
 }
 }  // namespace
 
-bool gsr_profile_on() { return g_prof_on; }
+bool gsr_profile_on() { return g_prof_mask != 0; }
 void gsr_profile_begin(int kernel, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!((g_prof_mask >> kernel) & 1u)) return;
     KernelProf& k = g_prof[kernel];
     if (k.pending.size() >= kMaxPending || k.open) return;
     hipEvent_t e;
@@ -70,7 +71,7 @@ void gsr_profile_end(int kernel, hipStream_t s) {
     k.pending.emplace_back(k.open, e);
     k.open = nullptr;
 }
-extern "C" void gsr_profile_enable(int32_t on) { g_prof_on = on != 0; }
+extern "C" void gsr_profile_enable(int32_t mask) { g_prof_mask = (uint32_t)mask; }
 extern "C" void gsr_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& k : g_prof) { prof_drain(k); k.total_ms = 0.0; k.launches = 0; }

@@ -1,0 +1,125 @@
+"""render(): the reference's L2 boundary, signature kept verbatim
+(gaussian_renderer/__init__.py:19 of alevalve/gaussmart):
+
+    render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None) -> dict
+    keys: render, viewspace_points, visibility_filter, radii, rend_alpha, rend_normal, rend_dist,
+          surf_depth, surf_normal
+
+Device follows the model's tensors (the reference hard-codes "cuda").
+"""
+import math
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .sh import eval_sh
+
+
+def _camera_rays(view, device, dtype):
+    """Per-pixel ray directions / origin in world space (utils/point_utils.py:9-24), cached on the
+    camera because they only depend on it."""
+    cache = getattr(view, "_gsr_rays", None)
+    key = (str(device), dtype, view.image_width, view.image_height)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    wvt = view.world_view_transform.to(device=device, dtype=dtype)
+    c2w = wvt.T.inverse()
+    W, H = view.image_width, view.image_height
+    ndc2pix = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]],
+                           dtype=dtype, device=device).T
+    proj = c2w.T @ view.full_proj_transform.to(device=device, dtype=dtype)
+    intrins = (proj @ ndc2pix)[:3, :3].T
+    gx, gy = torch.meshgrid(torch.arange(W, device=device, dtype=dtype),
+                            torch.arange(H, device=device, dtype=dtype), indexing="xy")
+    pix = torch.stack([gx, gy, torch.ones_like(gx)], dim=-1).reshape(-1, 3)
+    rays_d = pix @ intrins.inverse().T @ c2w[:3, :3].T
+    rays_o = c2w[:3, 3]
+    try:
+        view._gsr_rays = (key, rays_d, rays_o)
+    except Exception:
+        pass
+    return rays_d, rays_o
+
+
+def depths_to_points(view, depthmap):
+    rays_d, rays_o = _camera_rays(view, depthmap.device, depthmap.dtype)
+    return depthmap.reshape(-1, 1) * rays_d + rays_o
+
+
+def depth_to_normal(view, depth):
+    """Finite-difference normal of the back-projected depth map (utils/point_utils.py:26-37)."""
+    points = depths_to_points(view, depth).reshape(*depth.shape[1:], 3)
+    output = torch.zeros_like(points)
+    dx = points[2:, 1:-1] - points[:-2, 1:-1]
+    dy = points[1:-1, 2:] - points[1:-1, :-2]
+    output[1:-1, 1:-1, :] = torch.nn.functional.normalize(torch.cross(dx, dy, dim=-1), dim=-1)
+    return output
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+    xyz = pc.get_xyz
+    device = xyz.device
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height),
+        image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center,
+        prefiltered=False, debug=False)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    means3D, means2D, opacity = xyz, screenspace_points, pc.get_opacity
+    scales = rotations = cov3D_precomp = None
+    if getattr(pipe, "compute_cov3D_python", False):
+        # T matrix assembled in Python, rows (Tu, Tv, Tw) flattened: gaussian_renderer/__init__.py:62-75
+        splat2world = pc.get_covariance(scaling_modifier)
+        W, H = viewpoint_camera.image_width, viewpoint_camera.image_height
+        near, far = viewpoint_camera.znear, viewpoint_camera.zfar
+        ndc2pix = torch.tensor([[W / 2, 0, 0, (W - 1) / 2], [0, H / 2, 0, (H - 1) / 2],
+                                [0, 0, far - near, near], [0, 0, 0, 1]], dtype=torch.float32, device=device).T
+        world2pix = viewpoint_camera.full_proj_transform @ ndc2pix
+        cov3D_precomp = (splat2world[:, [0, 1, 3]] @ world2pix[:, [0, 1, 3]]).permute(0, 2, 1).reshape(-1, 9)
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+
+    shs = colors_precomp = None
+    if override_color is None:
+        if getattr(pipe, "convert_SHs_python", False) and False:   # the reference forces this off (:82)
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            d = xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
+            colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, d / d.norm(dim=1, keepdim=True)) + 0.5, 0.0)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+
+    rendered_image, radii, allmap = rasterizer(
+        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+
+    rets = {"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii}
+
+    render_alpha = allmap[1:2]
+    # view-space normals -> world space
+    render_normal = allmap[2:5]
+    render_normal = (render_normal.permute(1, 2, 0) @ (viewpoint_camera.world_view_transform[:3, :3].T)).permute(2, 0, 1)
+    render_depth_median = torch.nan_to_num(allmap[5:6], 0, 0)
+    render_depth_expected = torch.nan_to_num(allmap[0:1] / render_alpha, 0, 0)
+    render_dist = allmap[6:7]
+    # depth_ratio 1 = median depth (bounded scenes), 0 = expected depth (unbounded)
+    surf_depth = render_depth_expected * (1 - pipe.depth_ratio) + pipe.depth_ratio * render_depth_median
+    surf_normal = depth_to_normal(viewpoint_camera, surf_depth).permute(2, 0, 1)
+    surf_normal = surf_normal * render_alpha.detach()   # render_normal is un-normalised too
+
+    rets.update({"rend_alpha": render_alpha, "rend_normal": render_normal, "rend_dist": render_dist,
+                 "surf_depth": surf_depth, "surf_normal": surf_normal})
+    return rets

@@ -1,0 +1,99 @@
+"""One training iteration and the surrounding loop.
+
+Counterpart of training() in the reference (train.py:45-243): random view, render, loss
+0.8*L1 + 0.2*(1-SSIM) + lambda_normal*normal + lambda_dist*dist, backward, densification
+bookkeeping, Adam step.  The reference's per-iteration `.item()` calls, CSV append, TensorBoard,
+DINO scalar (no gradient, needs a network fetch), LPIPS and the viewer socket are left out: none
+of them reaches the rasterizer, and the host syncs they cause are a throughput hazard.
+"""
+import random
+import time
+
+import torch
+
+from .gaussian_renderer import render
+from .losses import l1_loss, ssim
+from .view_parallel import ViewParallel
+
+
+def training_losses(render_pkg, gt_image, opt, iteration):
+    image = render_pkg["render"]
+    Ll1 = l1_loss(image, gt_image)
+    loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim(image, gt_image))
+    lambda_normal = opt.lambda_normal if iteration > 7000 else 0.0
+    lambda_dist = opt.lambda_dist if iteration > 3000 else 0.0
+    normal_error = (1 - (render_pkg["rend_normal"] * render_pkg["surf_normal"]).sum(dim=0))[None]
+    normal_loss = lambda_normal * normal_error.mean()
+    dist_loss = lambda_dist * render_pkg["rend_dist"].mean()
+    total = loss + dist_loss + normal_loss
+    return total, {"l1": Ll1.detach(), "loss": loss.detach(), "normal": normal_loss.detach(), "dist": dist_loss.detach()}
+
+
+def training_step(gaussians, viewpoint_cam, gt_image, opt, pipe, background, iteration,
+                  view_parallel: ViewParallel = None, render_fn=render, step_optimizer=True):
+    """forward + loss + backward (+ gradient all-reduce) (+ Adam).  Returns (render_pkg, losses);
+    nothing is synchronised with the host."""
+    gaussians.update_learning_rate(iteration)
+    render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background)
+    total, parts = training_losses(render_pkg, gt_image, opt, iteration)
+    total.backward()
+    if view_parallel is not None:
+        view_parallel.allreduce_gradients()
+    if step_optimizer:
+        gaussians.optimizer.step()
+        gaussians.optimizer.zero_grad(set_to_none=True)
+    parts["total"] = total.detach()
+    return render_pkg, parts
+
+
+def densification_step(gaussians, render_pkg, opt, iteration, cameras_extent, white_background=False,
+                       view_parallel: ViewParallel = None):
+    """train.py:198-211: statistics every iteration, densify / prune every
+    `densification_interval`, opacity reset every `opacity_reset_interval`."""
+    if iteration >= opt.densify_until_iter:
+        return
+    with torch.no_grad():
+        vis, radii = render_pkg["visibility_filter"], render_pkg["radii"]
+        gaussians.max_radii2D[vis] = torch.max(gaussians.max_radii2D[vis], radii[vis].to(gaussians.max_radii2D.dtype))
+        gaussians.add_densification_stats(render_pkg["viewspace_points"], vis)
+        if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+            gen = None
+            if view_parallel is not None:
+                view_parallel.sync_densification_stats()
+                gen = view_parallel.replicated_generator(iteration, gaussians.get_xyz.device)
+            size_threshold = 20 if iteration > opt.opacity_reset_interval else None
+            gaussians.densify_and_prune(opt.densify_grad_threshold, opt.opacity_cull, cameras_extent,
+                                        size_threshold, generator=gen)
+        if iteration % opt.opacity_reset_interval == 0 or (white_background and iteration == opt.densify_from_iter):
+            gaussians.reset_opacity()
+
+
+def train(gaussians, cameras, opt, pipe, background, *, cameras_extent=1.0, first_iter=0, iterations=None,
+          view_parallel: ViewParallel = None, white_background=False, seed=0, log_every=0, log_fn=print):
+    """cameras: objects with .original_image [3,H,W].  Epochs are shuffled stacks popped at random,
+    as train.py:99-102; under view parallelism each rank pops from its shard of the same shuffle."""
+    iterations = opt.iterations if iterations is None else iterations
+    rng = random.Random(seed)
+    stack, epoch = None, 0
+    device = gaussians.get_xyz.device
+    t0 = time.time()
+    last = None
+    for iteration in range(first_iter + 1, iterations + 1):
+        if iteration % 1000 == 0:
+            gaussians.oneupSHdegree()
+        if not stack:
+            stack = list(view_parallel.shard_views(cameras, seed + epoch)) if view_parallel else list(cameras)
+            epoch += 1
+        cam = stack.pop(rng.randint(0, len(stack) - 1))
+        gt = cam.original_image.to(device)
+        # the optimizer step comes after the densification bookkeeping, as in the reference
+        render_pkg, last = training_step(gaussians, cam, gt, opt, pipe, background, iteration,
+                                         view_parallel=view_parallel, step_optimizer=False)
+        densification_step(gaussians, render_pkg, opt, iteration, cameras_extent, white_background, view_parallel)
+        if iteration < iterations:
+            gaussians.optimizer.step()
+            gaussians.optimizer.zero_grad(set_to_none=True)
+        if log_every and iteration % log_every == 0:
+            log_fn(f"[it {iteration}] loss {float(last['loss']):.5f} points {gaussians.get_xyz.shape[0]} "
+                   f"{(iteration - first_iter) / (time.time() - t0):.2f} it/s")
+    return last

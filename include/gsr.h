@@ -148,9 +148,11 @@ int32_t gsr_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uin
                            void* workspace, size_t workspace_bytes, gsr_stream_t stream);
 
 /* Opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline figures).
+ * `mask`: bit k enables kernel k in the order of the names below (-1 = all, 0 = off); timing only
+ * the few big kernels keeps the event overhead out of the measured step.
  * Kernel names: "preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
  * "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn". */
-void gsr_profile_enable(int32_t on);
+void gsr_profile_enable(int32_t mask);
 void gsr_profile_reset(void);
 int32_t gsr_profile_read(const char* kernel, double* total_ms, int32_t* launches);
 

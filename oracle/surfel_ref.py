@@ -223,21 +223,22 @@ def bin_tiles(xy_unused, radii: np.ndarray, rect: np.ndarray, depth_all: np.ndar
     ascending, tiles row-major inside the rect.  key = (tile << 32) | float32 bits of depth.
     Returns keys_sorted u64 [D], point_list u32 [D], ranges u32 [tiles,2] (zeros when empty).
     """
-    vis = np.nonzero(radii > 0)[0]
-    keys, vals = [], []
     dbits = depth_all.astype(np.float32).view(np.uint32).astype(np.uint64)
-    for i in vis:
-        x0, y0, x1, y1 = (int(v) for v in rect[i])
-        if x1 <= x0 or y1 <= y0:
-            continue
-        ys, xs = np.meshgrid(np.arange(y0, y1), np.arange(x0, x1), indexing="ij")
-        tid = (ys * grid_x + xs).reshape(-1).astype(np.uint64)
-        keys.append((tid << np.uint64(32)) | dbits[i])
-        vals.append(np.full(tid.shape, i, dtype=np.uint32))
-    if not keys:
+    rect = rect.astype(np.int64)
+    w = np.where(radii > 0, rect[:, 2] - rect[:, 0], 0)
+    h = np.where(radii > 0, rect[:, 3] - rect[:, 1], 0)
+    cnt = np.maximum(w, 0) * np.maximum(h, 0)
+    total = int(cnt.sum())
+    if total == 0:
         return np.zeros(0, np.uint64), np.zeros(0, np.uint32)
-    keys = np.concatenate(keys)
-    vals = np.concatenate(vals)
+    gid = np.repeat(np.arange(radii.shape[0]), cnt)              # Gaussian of each instance
+    first = np.repeat(np.cumsum(cnt) - cnt, cnt)
+    local = np.arange(total) - first                             # row-major index inside the rect
+    wy = np.repeat(w, cnt)
+    ty = rect[gid, 1] + local // wy
+    tx = rect[gid, 0] + local % wy
+    keys = ((ty * grid_x + tx).astype(np.uint64) << np.uint64(32)) | dbits[gid]
+    vals = gid.astype(np.uint32)
     order = np.argsort(keys, kind="stable")
     return keys[order], vals[order]
 

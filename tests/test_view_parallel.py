@@ -1,0 +1,86 @@
+"""World-size-2 gloo test of the view-parallel path on CPU: one replica per rank, different
+views, one flat all-reduce of the per-Gaussian gradients, replicated densification."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gaussmart_amd import gaussian_renderer
+    from gaussmart_amd.gaussian_model import GaussianModel
+    from gaussmart_amd.params import OptimizationParams, PipelineParams
+    from gaussmart_amd.synthetic import make_scene, jittered_cameras
+    from gaussmart_amd.trainer import training_step, densification_step
+    from gaussmart_amd.view_parallel import ViewParallel
+    from oracle import surfel_ref as O
+    gaussian_renderer.GaussianRasterizer = O.OracleRasterizer      # test-only stand-in for the HIP operator
+
+    params, _ = make_scene(150, 48, 48, seed=0)
+    cams = jittered_cameras(world, 48, 48, seed=0, device="cpu")
+    gt = torch.rand(3, 48, 48, generator=torch.Generator().manual_seed(5))
+    opt, pipe, bg = OptimizationParams(), PipelineParams(), torch.zeros(3)
+
+    m = GaussianModel(3, device="cpu"); m.use_fused_adam = False
+    m.create_from_params(params); m.training_setup(opt)
+    vp = ViewParallel(m)
+    assert vp.world_size == world and vp.rank == rank
+    shard = vp.shard_views(list(range(10)), epoch_seed=3)
+    pkg, _ = training_step(m, cams[rank], gt, opt, pipe, bg, 601, view_parallel=vp, step_optimizer=False)
+    grads = [p.grad.clone() for p in m.parameters()]
+    # densification with synced statistics and a replicated generator
+    for it in (601, 700):
+        if it != 601:
+            pkg, _ = training_step(m, cams[rank], gt, opt, pipe, bg, it, view_parallel=vp, step_optimizer=False)
+        densification_step(m, pkg, opt, it, cameras_extent=5.0, view_parallel=vp)
+        m.optimizer.step(); m.optimizer.zero_grad(set_to_none=True)
+    torch.save({"grads": grads, "shard": shard, "xyz": m.get_xyz.detach().clone(), "n": m.get_xyz.shape[0]},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_view_parallel_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    r = [torch.load(os.path.join(tmp_path, f"rank{i}.pt")) for i in range(world)]
+    # identical averaged gradients and identical replicas after a synced densify step
+    for a, b in zip(r[0]["grads"], r[1]["grads"]):
+        assert torch.equal(a, b)
+    assert r[0]["n"] == r[1]["n"] and torch.equal(r[0]["xyz"], r[1]["xyz"])
+    assert sorted(r[0]["shard"] + r[1]["shard"]) == list(range(10)) and not set(r[0]["shard"]) & set(r[1]["shard"])
+
+    # the all-reduced gradient is the mean of the two single-view gradients
+    from gaussmart_amd import gaussian_renderer
+    from gaussmart_amd.gaussian_model import GaussianModel
+    from gaussmart_amd.params import OptimizationParams, PipelineParams
+    from gaussmart_amd.synthetic import make_scene, jittered_cameras
+    from gaussmart_amd.trainer import training_step
+    from oracle import surfel_ref as O
+    old = gaussian_renderer.GaussianRasterizer
+    gaussian_renderer.GaussianRasterizer = O.OracleRasterizer
+    try:
+        params, _ = make_scene(150, 48, 48, seed=0)
+        cams = jittered_cameras(world, 48, 48, seed=0, device="cpu")
+        gt = torch.rand(3, 48, 48, generator=torch.Generator().manual_seed(5))
+        single = []
+        for cam in cams:
+            m = GaussianModel(3, device="cpu"); m.use_fused_adam = False
+            m.create_from_params(params); m.training_setup(OptimizationParams())
+            training_step(m, cam, gt, OptimizationParams(), PipelineParams(), torch.zeros(3), 601, step_optimizer=False)
+            single.append([p.grad.clone() for p in m.parameters()])
+    finally:
+        gaussian_renderer.GaussianRasterizer = old
+    for k in range(6):
+        torch.testing.assert_close(r[0]["grads"][k], 0.5 * (single[0][k] + single[1][k]), rtol=1e-5, atol=1e-9)
