@@ -46,8 +46,20 @@ def _f32c(t, name, device):
     return t.contiguous()
 
 
+_PLACEHOLDER = {}
+
+
 def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    """Device pointer of a tensor; None -> NULL.  Empty tensors have a NULL data_ptr, but NULL means
+    "argument absent" in the C ABI, so they get the address of a small per-device placeholder."""
+    if t is None:
+        return C.c_void_p(0)
+    if t.numel() == 0:
+        ph = _PLACEHOLDER.get(t.device)
+        if ph is None:
+            ph = _PLACEHOLDER[t.device] = torch.zeros(64, dtype=torch.float32, device=t.device)
+        return C.c_void_p(ph.data_ptr())
+    return C.c_void_p(t.data_ptr())
 
 
 class _Allocator:

@@ -86,8 +86,7 @@ def test_preprocess_parity(gpu_device, n, w, h, seed):
     # clamp mask
     cl = torch.zeros(n, dtype=torch.int32)
     bits = (geom.clamped.to(torch.int32) * torch.tensor([1, 2, 4], dtype=torch.int32)).sum(1)
-    cl[geom.vis_idx] = bits
-    rgb_margin = torch.ones(n, dtype=torch.bool)
+    cl[geom.vis_idx] = bits.to(torch.int32)
     assert int((dbg["clamped"].cpu()[vi] != cl[vi]).sum()) <= 2
 
 
@@ -204,7 +203,7 @@ def test_backward_parity_precomputed_colors_and_transmat(gpu_device):
     T[geom.vis_idx] = geom.Tm.reshape(-1, 9)
     b = dict(means3D=a["means3D"], opacities=a["opacities"], colors_precomp=torch.rand(1200, 3), cov3D_precomp=T)
     stats, (c_h, c_o) = _grad_compare(b, cam, gpu_device, 3)
-    assert float((c_h.double() - c_o).abs().max()) < 5e-3
+    assert float((c_h.double() - c_o.detach()).abs().max()) < 5e-3
     for k, s in stats.items():
         assert s["normwise"] < 1e-3 and s["median"] < 1e-4 and s["p99"] < 2e-3, (k, s)
 
