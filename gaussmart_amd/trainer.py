@@ -12,14 +12,25 @@ import time
 import torch
 
 from .gaussian_renderer import render
+from .fused_loss import photometric_loss as fused_photometric_loss
 from .losses import l1_loss, ssim
 from .view_parallel import ViewParallel
 
 
+def photometric(image, gt_image, lambda_dssim):
+    """(1-l)*L1 + l*(1-SSIM), train.py:113-114.  Device tensors go through the fused HIP kernels
+    (gaussmart_amd/fused_loss.py); host tensors (the CPU plumbing tests) through the stock torch
+    formulation the reference itself uses (utils/loss_utils.py)."""
+    if image.is_cuda:
+        loss, Ll1, _ = fused_photometric_loss(image, gt_image, lambda_dssim)
+        return loss, Ll1
+    Ll1 = l1_loss(image, gt_image)
+    return (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - ssim(image, gt_image)), Ll1
+
+
 def training_losses(render_pkg, gt_image, opt, iteration):
     image = render_pkg["render"]
-    Ll1 = l1_loss(image, gt_image)
-    loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim(image, gt_image))
+    loss, Ll1 = photometric(image, gt_image, opt.lambda_dssim)
     lambda_normal = opt.lambda_normal if iteration > 7000 else 0.0
     lambda_dist = opt.lambda_dist if iteration > 3000 else 0.0
     normal_error = (1 - (render_pkg["rend_normal"] * render_pkg["surf_normal"]).sum(dim=0))[None]

@@ -147,11 +147,26 @@ int32_t gsr_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uin
                            uint32_t* vals_out, int32_t n, int32_t begin_bit, int32_t end_bit,
                            void* workspace, size_t workspace_bytes, gsr_stream_t stream);
 
+/* Fused photometric loss: (1-lambda)*mean|x-y| + lambda*(1 - mean SSIM(x,y)) with
+ * the reference's SSIM (utils/loss_utils.py:38-57: 11x11 Gaussian window sigma 1.5, zero padding)
+ * as used at train.py:113-114.  img, gt: device f32 [C,H,W].
+ * forward : writes maps f32[3,C,H,W] (partials of SSIM kept for the backward) and
+ *           partials f32[gsr_loss_num_partials(H,W)] = per-block (sum SSIM, sum |x-y|) pairs which
+ *           the caller adds up (fixed order => reproducible loss value).
+ * backward: dimg f32[C,H,W] = grad_scale[0] * dloss/dimg (grad_scale is a DEVICE scalar, so no
+ *           host sync is needed to chain it). */
+int32_t gsr_loss_num_partials(int32_t H, int32_t W);
+int32_t gsr_loss_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W,
+                         float* maps, float* partials, gsr_stream_t stream);
+int32_t gsr_loss_backward(const float* img, const float* gt, const float* maps, int32_t C, int32_t H,
+                          int32_t W, float lambda_dssim, const float* grad_scale, float* dimg,
+                          gsr_stream_t stream);
+
 /* Opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline figures).
  * `mask`: bit k enables kernel k in the order of the names below (-1 = all, 0 = off); timing only
  * the few big kernels keeps the event overhead out of the measured step.
  * Kernel names: "preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
- * "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn". */
+ * "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "loss_fwd", "loss_bwd". */
 void gsr_profile_enable(int32_t mask);
 void gsr_profile_reset(void);
 int32_t gsr_profile_read(const char* kernel, double* total_ms, int32_t* launches);
