@@ -36,7 +36,9 @@ struct GsrProfileScope {
 
 // ---------------------------------------------------------------- buffer layouts
 // One "splat record" per Gaussian, written by preprocess_fwd and gathered by the render kernels
-// in 16-byte pieces: [Tu.xyz Tv.xyz Tw.xyz | xy | n.xyz opa | rgb | depth pad]
+// in 16-byte pieces: [Tu.xyz Tv.xyz Tw.xyz | xy | n.xyz opa | rgb | cull rect (4 x int16)]
+// The cull rect is a conservative pixel bounding box of {alpha >= 1/255}: pairs outside it are
+// skipped by the per-pixel alpha test anyway, so whole waves can skip the splat without evaluating it.
 #define GSR_SPLAT_FLOATS 20
 #define GSR_SP_TU 0
 #define GSR_SP_TV 3
@@ -45,7 +47,7 @@ struct GsrProfileScope {
 #define GSR_SP_NRM 11
 #define GSR_SP_OPA 14
 #define GSR_SP_RGB 15
-#define GSR_SP_DEPTH 18
+#define GSR_SP_RECT 18   // two 32-bit words: (x0 | x1 << 16), (y0 | y1 << 16), signed 16-bit each
 
 // One gradient row per (Gaussian, tile) instance, written by render_bwd, summed by
 // preprocess_bwd: [dTu.xyz dTv.xyz dTw.xyz | dxy | dn.xyz | dopa | drgb | pad pad]
@@ -128,6 +130,12 @@ int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int
 #ifdef __HIPCC__
 // v_rcp_f32 (1 ulp); the parity budget is 1e-4 relative
 __device__ __forceinline__ float gsr_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// does the splat's cull rect (packed words wx, wy) overlap the pixel box [bx0, bx0+7] x [by0, by0+7]?
+__device__ __forceinline__ bool gsr_rect_overlaps_quad(uint32_t wx, uint32_t wy, int bx0, int by0) {
+    const int x0 = (int)(short)(wx & 0xFFFFu), x1 = (int)(short)(wx >> 16);
+    const int y0 = (int)(short)(wy & 0xFFFFu), y1 = (int)(short)(wy >> 16);
+    return x0 <= bx0 + 7 && x1 >= bx0 && y0 <= by0 + 7 && y1 >= by0;
+}
 __device__ __forceinline__ void gsr_tile_rect(float cx, float cy, int radius, int gx, int gy,
                                               int& x0, int& y0, int& x1, int& y1) {
     // (int) casts truncate toward zero exactly like the recalled getRect

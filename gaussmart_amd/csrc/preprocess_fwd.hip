@@ -1,6 +1,6 @@
 // K1 preprocess_fwd: one thread per Gaussian.
 //   view cull -> quat -> T (splat->pixel homography, rows Tu,Tv,Tw) -> AABB radius + tile rect
-//   -> view-space normal -> SH colour (+clamp mask) -> 80-byte splat record.
+//   -> view-space normal -> SH colour (+clamp mask) -> alpha-support cull rect -> 80-byte splat record.
 // Restates the [U] preprocess of the un-vendored rasterizer; in-tree anchors:
 //   T matrix / (W-1)/2 convention   gaussian_renderer/__init__.py:64-75
 //   quaternion -> R                 utils/general_utils.py:78-99
@@ -176,12 +176,50 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
         rgb = make_float3(p.colors[3 * idx], p.colors[3 * idx + 1], p.colors[3 * idx + 2]);
     }
 
+    // conservative pixel box of {pixels where alpha can reach 1/255}:
+    //   alpha = opa * exp(-rho/2) >= 1/255  <=>  rho = min(rho3d, rho2d) <= rho_max = 2 ln(255 opa)
+    //   rho2d <= rho_max : disc of radius sqrt(rho_max / 2) around the AABB centre
+    //   rho3d <= rho_max : projection of the splat-space disc of radius sqrt(rho_max), bounded with the
+    //                      same conic formula as the 3-sigma AABB (valid while the disc stays in front
+    //                      of the camera plane, d < 0; otherwise no culling)
+    uint32_t rect_x = 0x7FFF8000u, rect_y = 0x7FFF8000u;   // [-32768, 32767]: never culled
+    {
+        const float opa = p.opac[idx];
+        const float c2 = (fmaxf(2.0f * logf(255.0f * opa), 0.0f) + 0.05f) * 1.02f;
+        if (255.0f * opa < 0.999f) {
+            rect_x = 0x80007FFFu; rect_y = 0x80007FFFu;     // x0 = 32767 > x1 = -32768: cannot reach 1/255 anywhere
+        } else {
+            const float dd = c2 * (Tw[0] * Tw[0] + Tw[1] * Tw[1]) - Tw[2] * Tw[2];
+            if (dd < 0.0f) {
+                const float idd = 1.0f / dd;
+                const float g0 = c2 * idd, g2 = -idd;
+                const float qx = g0 * (Tu[0] * Tw[0] + Tu[1] * Tw[1]) + g2 * Tu[2] * Tw[2];
+                const float qy = g0 * (Tv[0] * Tw[0] + Tv[1] * Tw[1]) + g2 * Tv[2] * Tw[2];
+                const float hx = sqrtf(fmaxf(qx * qx - (g0 * (Tu[0] * Tu[0] + Tu[1] * Tu[1]) + g2 * Tu[2] * Tu[2]), 0.0f));
+                const float hy = sqrtf(fmaxf(qy * qy - (g0 * (Tv[0] * Tv[0] + Tv[1] * Tv[1]) + g2 * Tv[2] * Tv[2]), 0.0f));
+                const float r2 = sqrtf(0.5f * c2);
+                float lox = fminf(qx - hx, cx - r2), hix = fmaxf(qx + hx, cx + r2);
+                float loy = fminf(qy - hy, cy - r2), hiy = fmaxf(qy + hy, cy + r2);
+                const float mx = 1.0f + 0.01f * (hix - lox), my = 1.0f + 0.01f * (hiy - loy);
+                lox -= mx; hix += mx; loy -= my; hiy += my;
+                if (isfinite(lox) && isfinite(hix) && isfinite(loy) && isfinite(hiy)) {
+                    const int x0 = (int)fminf(fmaxf(floorf(lox), -32768.f), 32767.f);
+                    const int x1 = (int)fminf(fmaxf(ceilf(hix), -32768.f), 32767.f);
+                    const int y0 = (int)fminf(fmaxf(floorf(loy), -32768.f), 32767.f);
+                    const int y1 = (int)fminf(fmaxf(ceilf(hiy), -32768.f), 32767.f);
+                    rect_x = ((uint32_t)x0 & 0xFFFFu) | ((uint32_t)x1 << 16);
+                    rect_y = ((uint32_t)y0 & 0xFFFFu) | ((uint32_t)y1 << 16);
+                }
+            }
+        }
+    }
+
     float4* rec = reinterpret_cast<float4*>(p.splat + (size_t)idx * GSR_SPLAT_FLOATS);
     rec[0] = make_float4(Tu[0], Tu[1], Tu[2], Tv[0]);
     rec[1] = make_float4(Tv[1], Tv[2], Tw[0], Tw[1]);
     rec[2] = make_float4(Tw[2], cx, cy, nrm[0]);
     rec[3] = make_float4(nrm[1], nrm[2], p.opac[idx], rgb.x);
-    rec[4] = make_float4(rgb.y, rgb.z, vz, 0.0f);
+    rec[4] = make_float4(rgb.y, rgb.z, __uint_as_float(rect_x), __uint_as_float(rect_y));
     p.clamped[idx] = clamp_bits;
     p.radii[idx] = (int)radius;
     p.tiles[idx] = (uint32_t)ntiles;

@@ -34,27 +34,59 @@ struct RenderBwdParams {
     float* grad_rows;
 };
 
-// ---- DPP helpers -------------------------------------------------------------------------------
+// ---- wave64 reductions -----------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    // v + dpp(v); lanes whose source is disabled/out of range contribute 0 (bound_ctrl)
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
-    return v + __int_as_float(moved);
+__device__ __forceinline__ float dpp_move(float v) {
+    // lanes whose source is disabled/out of range receive 0 (bound_ctrl)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
 }
-// Sum over the 64 lanes; the total is valid in lane 63.
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
-    v = dpp_add<0x140, 0xf>(v);   // row_mirror   -> every lane holds its row's sum
-    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3 += previous row
-    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3 += lane 31
+typedef unsigned int gsr_u2 __attribute__((ext_vector_type(2)));
+
+// "Transposed butterfly": sums 16 per-lane values over the 64 lanes in 6 stages while HALVING the
+// number of live registers at each of the first four (gfx950 v_permlane32_swap / v_permlane16_swap,
+// then DPP row_ror:8 and row_half_mirror with a select).  ~50 VALU instead of 16 x 6 DPP steps.
+// On return every lane l holds the wave total of v[l >> 2].
+__device__ __forceinline__ float wave_sum16_transposed(const float (&v)[16], int lane) {
+    float r[8], q[4], p[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {      // bit 5: lanes < 32 keep v[i], lanes >= 32 keep v[i+8]
+        const gsr_u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
+        r[i] = __uint_as_float(t.x) + __uint_as_float(t.y);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {      // bit 4: even rows keep r[i], odd rows keep r[i+4]
+        const gsr_u2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[i]), __float_as_uint(r[i + 4]), false, false);
+        q[i] = __uint_as_float(t.x) + __uint_as_float(t.y);
+    }
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {      // bit 3: partner is lane ^ 8 (row_ror:8)
+        const float keep = b3 ? q[i + 2] : q[i], send = b3 ? q[i] : q[i + 2];
+        p[i] = keep + dpp_move<0x128, 0xf>(send);
+    }
+    {                                   // bit 2: partner is lane ^ 7 inside each group of 8 (row_half_mirror)
+        const float keep = b2 ? p[1] : p[0], send = b2 ? p[0] : p[1];
+        p[0] = keep + dpp_move<0x141, 0xf>(send);
+    }
+    p[0] += dpp_move<0xB1, 0xf>(p[0]);  // quad_perm [1,0,3,2]
+    p[0] += dpp_move<0x4E, 0xf>(p[0]);  // quad_perm [2,3,0,1]
+    return p[0];
+}
+// Two values: on return lanes 16..31 hold the wave total of a, lanes 48..63 that of b.
+__device__ __forceinline__ float wave_sum2(float a, float b) {
+    const gsr_u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    float v = __uint_as_float(t.x) + __uint_as_float(t.y);
+    v += dpp_move<0xB1, 0xf>(v);
+    v += dpp_move<0x4E, 0xf>(v);
+    v += dpp_move<0x141, 0xf>(v);   // row_half_mirror
+    v += dpp_move<0x140, 0xf>(v);   // row_mirror: every lane holds its row's sum
+    v += dpp_move<0x142, 0xa>(v);   // row_bcast:15: rows 1 and 3 add the previous row
     return v;
 }
 
 __global__ void __launch_bounds__(RB_BLOCK) render_bwd_kernel(RenderBwdParams p) {
     __shared__ float4 s_rec[RB_BATCH * 5];
-    __shared__ float4 s_acc[RB_WAVES][RB_BATCH][RB_ROW / 4];
+    __shared__ __attribute__((aligned(16))) float s_acc[RB_WAVES][RB_BATCH][RB_ROW];
     __shared__ unsigned long long s_touched[RB_WAVES];
     __shared__ uint32_t s_row[RB_BATCH];
     __shared__ uint32_t s_max_contrib;
@@ -76,6 +108,8 @@ __global__ void __launch_bounds__(RB_BLOCK) render_bwd_kernel(RenderBwdParams p)
 
     const bool clamp_pass = (p.flags & GSR_FLAG_CLAMP_PASSTHROUGH) != 0;
     const bool filter_depth_quirk = (p.flags & GSR_FLAG_FILTER_DEPTH_GRAD) != 0;
+    const bool no_cull = (p.flags & (uint32_t)GSR_FLAG_DEBUG_NO_CULL) != 0;
+    const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
 
     // per-pixel state saved by the forward
     const float T_final = inside ? p.final_T[pix_id] : 0.f;
@@ -142,7 +176,16 @@ __global__ void __launch_bounds__(RB_BLOCK) render_bwd_kernel(RenderBwdParams p)
         __syncthreads();
 
         unsigned long long touched = 0ull;
-        for (int j = 0; j < nb; ++j) {
+        // which staged splats can reach alpha >= 1/255 inside this wave's 8x8 quad at all?
+        bool ov = false;
+        if (lane < nb) {
+            const float4 r4 = s_rec[lane * 5 + 4];
+            ov = no_cull || gsr_rect_overlaps_quad(__float_as_uint(r4.z), __float_as_uint(r4.w), qx0, qy0);
+        }
+        unsigned long long todo_mask = __ballot(ov);
+        while (todo_mask) {
+            const int j = __builtin_ctzll(todo_mask);
+            todo_mask &= todo_mask - 1;
             const int cidx = hi - 1 - j;            // 0-based position in the tile list
             const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
             const float4 a3 = s_rec[j * 5 + 3];
@@ -229,20 +272,17 @@ __global__ void __launch_bounds__(RB_BLOCK) render_bwd_kernel(RenderBwdParams p)
                 }
             }
 
-            // wave-level sums (lane 63 ends up with the totals) -> this wave's LDS slot
-#pragma unroll
-            for (int k = 0; k < 9; ++k) gT[k] = wave_sum_to_lane63(gT[k]);
-            gxy0 = wave_sum_to_lane63(gxy0); gxy1 = wave_sum_to_lane63(gxy1);
-            gn0 = wave_sum_to_lane63(gn0); gn1 = wave_sum_to_lane63(gn1); gn2 = wave_sum_to_lane63(gn2);
-            gopa = wave_sum_to_lane63(gopa);
-            gc0 = wave_sum_to_lane63(gc0); gc1 = wave_sum_to_lane63(gc1); gc2 = wave_sum_to_lane63(gc2);
-            if (lane == 63) {
-                float4* slot = &s_acc[wave][j][0];
-                slot[0] = make_float4(gT[0], gT[1], gT[2], gT[3]);
-                slot[1] = make_float4(gT[4], gT[5], gT[6], gT[7]);
-                slot[2] = make_float4(gT[8], gxy0, gxy1, gn0);
-                slot[3] = make_float4(gn1, gn2, gopa, gc0);
-                slot[4] = make_float4(gc1, gc2, 0.f, 0.f);
+            // wave-level sums -> this wave's LDS slot (row layout GSR_GR_*)
+            {
+                const float v16[16] = {gT[0], gT[1], gT[2], gT[3], gT[4], gT[5], gT[6], gT[7], gT[8],
+                                       gn0, gn1, gn2, gopa, gc0, gc1, gc2};
+                const float tot = wave_sum16_transposed(v16, lane);
+                const float xy = wave_sum2(gxy0, gxy1);
+                float* slot = &s_acc[wave][j][0];
+                const int vi = lane >> 2;
+                if ((lane & 3) == 0) slot[vi < 9 ? vi : vi + 2] = tot;      // skip the two xy columns
+                if (lane == 16) slot[GSR_GR_XY] = xy;
+                if (lane == 48) slot[GSR_GR_XY + 1] = xy;
             }
         }
         if (lane == 0) s_touched[wave] = touched;
@@ -257,10 +297,10 @@ __global__ void __launch_bounds__(RB_BLOCK) render_bwd_kernel(RenderBwdParams p)
 #pragma unroll
                 for (int w = 0; w < RB_WAVES; ++w) {
                     if ((s_touched[w] >> j) & 1ull) {
-                        const float4 v = s_acc[w][j][q];
+                        const float4 v = *reinterpret_cast<const float4*>(&s_acc[w][j][4 * q]);
                         s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
                         if (q == 0) {
-                            const float4 u = s_acc[w][j][4];
+                            const float4 u = *reinterpret_cast<const float4*>(&s_acc[w][j][16]);
                             s1.x += u.x; s1.y += u.y; s1.z += u.z; s1.w += u.w;
                         }
                     }

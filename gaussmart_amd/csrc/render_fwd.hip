@@ -6,8 +6,10 @@
 // MI355X mapping: the tile's 4 wave64s each own an 8x8 pixel quad (compact footprint => a small
 // splat touches few waves and whole-wave skips are common).  Per round the workgroup gathers up to
 // 256 splat records (80 B, five 16-byte loads per thread) into LDS; the inner loop reads them with
-// wave-uniform (broadcast) ds_read_b128.  A wave whose 64 pixels are all done skips the inner loop;
-// the workgroup leaves once every pixel is done.
+// wave-uniform (broadcast) ds_read_b128.  Per 64 staged splats each lane tests ONE splat's cull rect
+// against the wave's quad and a 64-bit ballot becomes the list of splats the wave has to look at at
+// all (s_ff1 iteration): splats that cannot reach alpha >= 1/255 in the quad cost nothing.  A wave
+// whose 64 pixels are all done leaves the round; the workgroup leaves once every pixel is done.
 #include "gsr_common.h"
 #include "pair_eval.h"
 
@@ -16,6 +18,7 @@
 
 struct RenderFwdParams {
     int W, H, gx;
+    uint32_t flags;
     const uint32_t* ranges; const uint32_t* point_list; const float* splat;
     const float* bg;
     float* final_T; uint32_t* n_contrib; float* out_color; float* out_allmap;
@@ -41,7 +44,9 @@ __global__ void __launch_bounds__(RF_BLOCK) render_fwd_kernel(RenderFwdParams p)
 
     bool done = !inside;
     float T = 1.0f;
-    uint32_t contributor = 0, last_contributor = 0;
+    uint32_t last_contributor = 0;
+    const bool no_cull = (p.flags & (uint32_t)GSR_FLAG_DEBUG_NO_CULL) != 0;
+    const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
     float N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float Dacc = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med_depth = 0.f;
@@ -58,32 +63,46 @@ __global__ void __launch_bounds__(RF_BLOCK) render_fwd_kernel(RenderFwdParams p)
         }
         __syncthreads();
         const int nb = min(RF_BATCH, todo);
-        for (int j = 0; j < nb; ++j) {
-            // every lane is active here (j is wave-uniform), so the vote sees the whole wave
-            if (__all(done)) break;
-            if (done) continue;
-            ++contributor;
-            const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
-            const float4 a3 = s_rec[j * 5 + 3];
-            GsrPair pr;
-            if (!gsr_pair_eval(pxf, pyf, a0, a1, a2, a3.z, pr)) continue;
-            const float alpha = pr.alpha, depth = pr.depth;
-            const float test_T = T * (1.0f - alpha);
-            if (test_T < GSR_T_EPS) { done = true; continue; }
-            const float4 a4 = s_rec[j * 5 + 4];
-            const float w = alpha * T;
-            const float A = 1.0f - T;
-            float dm_dz_unused;
-            const float m = gsr_depth_map(depth, dm_dz_unused);
-            dist += (m * m * A + M2 - 2.0f * m * M1) * w;
-            Dacc += depth * w;
-            M1 += m * w;
-            M2 += m * m * w;
-            if (T > 0.5f) { med_depth = depth; med_contrib = contributor; }
-            N0 += a2.w * w; N1 += a3.x * w; N2 += a3.y * w;
-            C0 += a3.w * w; C1 += a4.x * w; C2 += a4.y * w;
-            T = test_T;
-            last_contributor = contributor;
+        bool wave_done = false;
+        for (int jbase = 0; jbase < nb && !wave_done; jbase += 64) {
+            // one ballot per 64 staged splats: which of them can reach alpha >= 1/255 inside this
+            // wave's 8x8 pixel quad at all (conservative cull rect from preprocess_fwd)?
+            const int jj = jbase + lane;
+            bool ov = false;
+            if (jj < nb) {
+                const float4 r4 = s_rec[jj * 5 + 4];
+                ov = no_cull || gsr_rect_overlaps_quad(__float_as_uint(r4.z), __float_as_uint(r4.w), qx0, qy0);
+            }
+            unsigned long long m = __ballot(ov);
+            while (m) {
+                // every lane is active here (the loop is wave-uniform), so the vote sees the whole wave
+                if (__all(done)) { wave_done = true; break; }
+                const int j = jbase + __builtin_ctzll(m);
+                m &= m - 1;
+                if (done) continue;
+                const uint32_t contributor = (uint32_t)(rd * RF_BATCH + j + 1);   // 1-based list position
+                const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
+                const float4 a3 = s_rec[j * 5 + 3];
+                GsrPair pr;
+                if (!gsr_pair_eval(pxf, pyf, a0, a1, a2, a3.z, pr)) continue;
+                const float alpha = pr.alpha, depth = pr.depth;
+                const float test_T = T * (1.0f - alpha);
+                if (test_T < GSR_T_EPS) { done = true; continue; }
+                const float4 a4 = s_rec[j * 5 + 4];
+                const float w = alpha * T;
+                const float A = 1.0f - T;
+                float dm_dz_unused;
+                const float m_d = gsr_depth_map(depth, dm_dz_unused);
+                dist += (m_d * m_d * A + M2 - 2.0f * m_d * M1) * w;
+                Dacc += depth * w;
+                M1 += m_d * w;
+                M2 += m_d * m_d * w;
+                if (T > 0.5f) { med_depth = depth; med_contrib = contributor; }
+                N0 += a2.w * w; N1 += a3.x * w; N2 += a3.y * w;
+                C0 += a3.w * w; C1 += a4.x * w; C2 += a4.y * w;
+                T = test_T;
+                last_contributor = contributor;
+            }
         }
     }
 
@@ -110,7 +129,7 @@ int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const uint32
                           const float* splat, float* final_T, uint32_t* n_contrib,
                           float* out_color, float* out_allmap, hipStream_t s) {
     RenderFwdParams p;
-    p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE;
+    p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE; p.flags = v.flags;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
     p.ranges = ranges; p.point_list = point_list; p.splat = splat; p.bg = v.bg;
     p.final_T = final_T; p.n_contrib = n_contrib; p.out_color = out_color; p.out_allmap = out_allmap;

@@ -48,7 +48,8 @@ enum {
 enum {
     GSR_FLAG_CLAMP_PASSTHROUGH = 1, /* gradient flows through alpha = min(0.99, o*G) when clamped */
     GSR_FLAG_FILTER_DEPTH_GRAD = 2, /* low-pass branch: dL/dz also added to dL/dTw.x,.y times s   */
-    GSR_FLAGS_UPSTREAM = 3
+    GSR_FLAGS_UPSTREAM = 3,
+    GSR_FLAG_DEBUG_NO_CULL = 4      /* test aid: ignore the per-wave cull rect (results are bit-identical) */
 };
 
 /* GaussianRasterizationSettings (gaussian_renderer/__init__.py:37-51) */

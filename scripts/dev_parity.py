@@ -30,8 +30,8 @@ radii_h = dbg["radii"].cpu()
 print("radii mismatches:", int((radii_h != geom.radii).sum()), "of", N)
 vi = geom.vis_idx
 sp = dbg["splat"].cpu()[vi]
-ref = torch.cat([geom.Tm.reshape(-1, 9), geom.xy, geom.normal, a["opacities"][vi], geom.rgb, geom.depth[:, None]], 1)
-err = (sp[:, :19] - ref).abs() / (ref.abs() + 1e-3)
+ref = torch.cat([geom.Tm.reshape(-1, 9), geom.xy, geom.normal, a["opacities"][vi], geom.rgb], 1)
+err = (sp[:, :18] - ref).abs() / (ref.abs() + 1e-3)
 print("splat max rel err per field:", err.max(0).values.numpy().round(7))
 
 # ---- binning bit-exact vs numpy on HIP's own K1 output
@@ -45,7 +45,7 @@ with np.errstate(all="ignore"):
     rect[:, 0] = np.clip(tdiv(cx - rad), 0, gx); rect[:, 1] = np.clip(tdiv(cy - rad), 0, gy)
     rect[:, 2] = np.clip(tdiv(cx + rad + 15), 0, gx); rect[:, 3] = np.clip(tdiv(cy + rad + 15), 0, gy)
 rect[~vis] = 0
-keys, plist = O.bin_tiles(None, rad, rect, spl[:, 18].copy(), gx)
+keys, plist = O.bin_tiles(None, rad, rect, dbg["depth_key"].cpu().numpy().view(np.float32).copy(), gx)
 ranges = O.tile_ranges(keys, gx*gy)
 pl_h = dbg["point_list"].cpu().numpy().astype(np.uint32)
 rg_h = dbg["ranges"].cpu().numpy().astype(np.uint32)

@@ -46,7 +46,8 @@ def _numpy_binning(dbg, W, H):
         rect[:, 0] = np.clip(t(cx - rf), 0, gx); rect[:, 1] = np.clip(t(cy - rf), 0, gy)
         rect[:, 2] = np.clip(t(cx + rf + np.float32(15)), 0, gx); rect[:, 3] = np.clip(t(cy + rf + np.float32(15)), 0, gy)
     rect[rad <= 0] = 0
-    keys, plist = O.bin_tiles(None, rad, rect, spl[:, 18].copy(), gx)
+    depth = dbg["depth_key"].cpu().numpy().view(np.float32).copy()
+    keys, plist = O.bin_tiles(None, rad, rect, depth, gx)
     return keys, plist, O.tile_ranges(keys, gx * gy), rect
 
 
@@ -74,11 +75,12 @@ def test_preprocess_parity(gpu_device, n, w, h, seed):
     vi = geom.vis_idx[(radii_h[geom.vis_idx] == geom.radii[geom.vis_idx])]
     sel = torch.isin(geom.vis_idx, vi)
     sp = dbg["splat"].cpu()[vi]
-    ref = torch.cat([geom.Tm.reshape(-1, 9), geom.xy, geom.normal, a["opacities"][geom.vis_idx], geom.rgb,
-                     geom.depth[:, None]], 1)[sel]
+    ref = torch.cat([geom.Tm.reshape(-1, 9), geom.xy, geom.normal, a["opacities"][geom.vis_idx], geom.rgb], 1)[sel]
     scale = ref.abs().amax(0).clamp_min(1e-3)
-    err = ((sp[:, :19] - ref).abs() / scale).amax(0)
+    err = ((sp[:, :18] - ref).abs() / scale).amax(0)
     assert float(err.max()) < 2e-5, err
+    depth_h = dbg["depth_key"].cpu().view(torch.float32)[vi]
+    assert float((depth_h - geom.depth[sel]).abs().max()) < 2e-5 * float(geom.depth.max())
     # tile counts follow from (centre, radius)
     _, _, _, rect = _numpy_binning(dbg, w, h)
     tiles_ref = (rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1])
@@ -232,6 +234,32 @@ def test_bitwise_deterministic(gpu_device):
         outs.append([c.detach(), am.detach(), r] + [ins[k].grad for k in ins] + [m2d.grad])
     for x, y in zip(*outs):
         assert torch.equal(x, y)       # no floating-point atomics anywhere: run-to-run bit identity
+
+
+@pytest.mark.parametrize("n,w,h,seed,opa", [(3000, 256, 256, 0, None), (3000, 250, 130, 1, 0.999), (3000, 256, 256, 2, 0.004),
+                                             (200000, 960, 540, 3, None), (500, 256, 256, 4, None)])
+def test_wave_culling_is_exact(gpu_device, n, w, h, seed, opa):
+    """The per-wave cull rect only skips pairs the alpha >= 1/255 test would reject anyway: outputs
+    and gradients must be BIT-identical with the culling disabled (GSR_FLAG_DEBUG_NO_CULL)."""
+    from gaussmart_amd.rasterizer import GaussianRasterizer
+    p, cam = make_scene(n, w, h, seed=seed, radius_px=40.0 if seed == 4 else 6.0)
+    a = _to(activate(p), gpu_device)
+    if opa is not None:
+        a["opacities"] = torch.full_like(a["opacities"], opa)
+    if seed == 4:   # huge, strongly tilted surfels, some crossing the camera plane
+        a["scales"] = a["scales"] * torch.tensor([1.0, 8.0], device=gpu_device)
+    outs = []
+    for flags in (3, 3 | 4):
+        ins = {k: v.clone().requires_grad_(True) for k, v in a.items()}
+        m2d = torch.zeros(n, 3, device=gpu_device, requires_grad=True)
+        c, r, am = GaussianRasterizer(hip_settings(cam, 3, (0.1, 0.2, 0.3), gpu_device), flags=flags)(
+            means3D=ins["means3D"], means2D=m2d, shs=ins["shs"], opacities=ins["opacities"], scales=ins["scales"],
+            rotations=ins["rotations"])
+        (c.square().sum() + am.sum()).backward()
+        outs.append([c.detach(), am.detach(), r] + [ins[k].grad for k in ins] + [m2d.grad])
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert float(outs[0][1][1].max()) > (0.0 if opa == 0.004 else 0.5)    # the scene is not trivially empty
 
 
 def test_edge_cases(gpu_device):
