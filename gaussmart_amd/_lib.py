@@ -23,7 +23,8 @@ GSR_FLAG_FILTER_DEPTH_GRAD = 2
 GSR_FLAGS_UPSTREAM = 3
 
 KERNEL_NAMES = ("preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
-                "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "loss_fwd", "loss_bwd")
+                "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "loss_fwd", "loss_bwd",
+                "regularizer_fwd", "regularizer_bwd")
 
 
 class GsrView(C.Structure):
@@ -112,6 +113,12 @@ def lib():
         L.gsr_loss_backward.restype = C.c_int32
         L.gsr_loss_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gsr_regularizer_forward.restype = C.c_int32
+        L.gsr_regularizer_forward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float,
+                                              C.c_void_p, C.c_void_p]
+        L.gsr_regularizer_backward.restype = C.c_int32
+        L.gsr_regularizer_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float,
+                                               C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gsr_profile_enable.restype = None
         L.gsr_profile_enable.argtypes = [C.c_int32]
         L.gsr_profile_reset.restype = None

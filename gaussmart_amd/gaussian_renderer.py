@@ -3,7 +3,10 @@
 
     render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None) -> dict
     keys: render, viewspace_points, visibility_filter, radii, rend_alpha, rend_normal, rend_dist,
-          surf_depth, surf_normal
+          surf_depth, surf_normal   (+ "allmap", the rasterizer's raw [7,H,W] side output)
+
+The extra keyword `surface_maps=False` skips the five derived maps: the trainer's fast path feeds
+`allmap` to the fused regularizer kernels instead (gaussmart_amd/fused_regularizer.py).
 
 Device follows the model's tensors (the reference hard-codes "cuda").
 """
@@ -56,7 +59,8 @@ def depth_to_normal(view, depth):
     return output
 
 
-def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, *,
+           surface_maps=True):
     xyz = pc.get_xyz
     device = xyz.device
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=device) + 0
@@ -106,7 +110,10 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
 
-    rets = {"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii}
+    rets = {"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii,
+            "allmap": allmap}
+    if not surface_maps:
+        return rets
 
     render_alpha = allmap[1:2]
     # view-space normals -> world space

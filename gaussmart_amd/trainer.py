@@ -13,6 +13,7 @@ import torch
 
 from .gaussian_renderer import render
 from .fused_loss import photometric_loss as fused_photometric_loss
+from .fused_regularizer import surface_regularizer
 from .losses import l1_loss, ssim
 from .view_parallel import ViewParallel
 
@@ -28,15 +29,27 @@ def photometric(image, gt_image, lambda_dssim):
     return (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - ssim(image, gt_image)), Ll1
 
 
-def training_losses(render_pkg, gt_image, opt, iteration):
+def training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam=None, pipe=None):
+    """train.py:113-143.  On a HIP device the photometric loss and the surface regularizers each run
+    as one fused kernel per direction; on the host (CPU plumbing tests) the stock torch formulation
+    of the reference is used on the maps render() derived."""
     image = render_pkg["render"]
     loss, Ll1 = photometric(image, gt_image, opt.lambda_dssim)
     lambda_normal = opt.lambda_normal if iteration > 7000 else 0.0
     lambda_dist = opt.lambda_dist if iteration > 3000 else 0.0
-    normal_error = (1 - (render_pkg["rend_normal"] * render_pkg["surf_normal"]).sum(dim=0))[None]
-    normal_loss = lambda_normal * normal_error.mean()
-    dist_loss = lambda_dist * render_pkg["rend_dist"].mean()
-    total = loss + dist_loss + normal_loss
+    if "rend_normal" in render_pkg:
+        normal_error = (1 - (render_pkg["rend_normal"] * render_pkg["surf_normal"]).sum(dim=0))[None]
+        normal_loss = lambda_normal * normal_error.mean()
+        dist_loss = lambda_dist * render_pkg["rend_dist"].mean()
+        total = loss + dist_loss + normal_loss
+    elif lambda_normal > 0.0 or lambda_dist > 0.0:
+        reg, normal_mean, dist_mean = surface_regularizer(render_pkg["allmap"], viewpoint_cam, pipe.depth_ratio,
+                                                          lambda_normal, lambda_dist)
+        normal_loss, dist_loss = lambda_normal * normal_mean, lambda_dist * dist_mean
+        total = loss + reg
+    else:
+        normal_loss = dist_loss = torch.zeros((), device=image.device)
+        total = loss
     return total, {"l1": Ll1.detach(), "loss": loss.detach(), "normal": normal_loss.detach(), "dist": dist_loss.detach()}
 
 
@@ -45,8 +58,9 @@ def training_step(gaussians, viewpoint_cam, gt_image, opt, pipe, background, ite
     """forward + loss + backward (+ gradient all-reduce) (+ Adam).  Returns (render_pkg, losses);
     nothing is synchronised with the host."""
     gaussians.update_learning_rate(iteration)
-    render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background)
-    total, parts = training_losses(render_pkg, gt_image, opt, iteration)
+    on_device = gaussians.get_xyz.is_cuda
+    render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=not on_device)
+    total, parts = training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam, pipe)
     total.backward()
     if view_parallel is not None:
         view_parallel.allreduce_gradients()

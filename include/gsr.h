@@ -163,11 +163,25 @@ int32_t gsr_loss_backward(const float* img, const float* gt, const float* maps, 
                           int32_t W, float lambda_dssim, const float* grad_scale, float* dimg,
                           gsr_stream_t stream);
 
+/* Fused surface regularizers: from the rasterizer's allmap [7,H,W] straight to
+ *   normal_loss = lambda_normal * mean(1 - rend_normal . surf_normal),  dist_loss = lambda_dist * mean(allmap[6])
+ * i.e. gaussian_renderer/__init__.py:117-156 + utils/point_utils.py:9-37 + train.py:132-140 of the
+ * reference.  kinv_host: HOST f32[9], row-major inverse of the pixel intrinsics the reference builds
+ * at utils/point_utils.py:11-17 (ray(x,y) = kinv * [x,y,1] in camera space).
+ * forward : partials f32[gsr_loss_num_partials(H,W)] = per-block (sum normal error, sum distortion).
+ * backward: d_allmap f32[7,H,W] = grad_scale[0] * d(normal_loss + dist_loss)/d(allmap), every
+ *           element written; grad_scale is a DEVICE scalar. */
+int32_t gsr_regularizer_forward(const float* allmap, int32_t H, int32_t W, const float* kinv_host,
+                                float depth_ratio, float* partials, gsr_stream_t stream);
+int32_t gsr_regularizer_backward(const float* allmap, int32_t H, int32_t W, const float* kinv_host,
+                                 float depth_ratio, float lambda_normal, float lambda_dist,
+                                 const float* grad_scale, float* d_allmap, gsr_stream_t stream);
+
 /* Opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline figures).
  * `mask`: bit k enables kernel k in the order of the names below (-1 = all, 0 = off); timing only
  * the few big kernels keeps the event overhead out of the measured step.
  * Kernel names: "preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
- * "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "loss_fwd", "loss_bwd". */
+ * "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "loss_fwd", "loss_bwd", "regularizer_fwd", "regularizer_bwd". */
 void gsr_profile_enable(int32_t mask);
 void gsr_profile_reset(void);
 int32_t gsr_profile_read(const char* kernel, double* total_ms, int32_t* launches);

@@ -1,0 +1,71 @@
+"""Fused surface regularizers (HIP) vs the oracle restatement of the reference's allmap
+post-processing + depth_to_normal + normal / distortion losses, and render()'s own torch maps."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import regularizer_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _allmap_from_render(dev, n=20000, w=320, h=240, seed=0):
+    from gaussmart_amd import gaussian_renderer
+    from gaussmart_amd.gaussian_model import GaussianModel
+    from gaussmart_amd.params import PipelineParams
+    from gaussmart_amd.synthetic import make_scene, jittered_cameras
+    params, _ = make_scene(n, w, h, seed=seed)
+    cam = jittered_cameras(2, w, h, seed=seed, device=dev)[1]          # a rotated / translated view
+    m = GaussianModel(3, device=dev)
+    m.create_from_params(params)
+    with torch.no_grad():
+        pkg = gaussian_renderer.render(cam, m, PipelineParams(), torch.zeros(3, device=dev))
+    return pkg, cam
+
+
+@pytest.mark.parametrize("depth_ratio,ln,ld", [(0.0, 0.05, 0.0), (1.0, 0.05, 1000.0), (0.3, 0.0, 100.0), (0.5, 1.0, 1.0)])
+def test_forward_backward_vs_oracle(gpu_device, depth_ratio, ln, ld):
+    from gaussmart_amd.fused_regularizer import surface_regularizer
+    pkg, cam = _allmap_from_render(gpu_device)
+    am = pkg["allmap"].detach()
+    amh = am.clone().requires_grad_(True)
+    loss, nm, dm = surface_regularizer(amh, cam, depth_ratio, ln, ld)
+    (2.5 * loss).backward()
+    amo = am.cpu().double().requires_grad_(True)
+    lo, nmo, dmo = R.regularizer_loss(amo, cam.world_view_transform.cpu().double(), cam.full_proj_transform.cpu().double(),
+                                      depth_ratio, ln, ld)
+    (2.5 * lo).backward()
+    np.testing.assert_allclose(nm.item(), nmo.item(), rtol=2e-5)
+    np.testing.assert_allclose(dm.item(), dmo.item(), rtol=2e-5)
+    np.testing.assert_allclose(loss.item(), lo.item(), rtol=2e-5, atol=1e-9)
+    gh, go = amh.grad.cpu().double(), torch.nan_to_num(amo.grad, 0.0, 0.0, 0.0)
+    for c in range(7):
+        sc = float(go[c].abs().max())
+        d = (gh[c] - go[c]).abs()
+        # fp32 cross products of nearly parallel finite differences lose digits on a few pixels
+        assert float(d.max()) <= 2e-3 * sc + 1e-12, (c, float(d.max()), sc)
+        assert float(d.mean()) <= 2e-5 * sc + 1e-14, (c, float(d.mean()), sc)
+
+
+def test_matches_render_maps(gpu_device):
+    """Same numbers as render()'s own (torch) surf_normal / rend_normal path on the device."""
+    from gaussmart_amd.fused_regularizer import surface_regularizer
+    pkg, cam = _allmap_from_render(gpu_device, seed=3)
+    normal_error = (1 - (pkg["rend_normal"] * pkg["surf_normal"]).sum(dim=0))
+    loss, nm, dm = surface_regularizer(pkg["allmap"], cam, 0.0, 0.05, 2.0)
+    np.testing.assert_allclose(nm.item(), normal_error.mean().item(), rtol=2e-5)
+    np.testing.assert_allclose(dm.item(), pkg["rend_dist"].mean().item(), rtol=2e-5)
+
+
+def test_empty_image_and_odd_sizes(gpu_device):
+    from gaussmart_amd.fused_regularizer import surface_regularizer
+    from gaussmart_amd.synthetic import jittered_cameras
+    cam = jittered_cameras(1, 37, 21, device=gpu_device)[0]
+    am = torch.zeros(7, 21, 37, device=gpu_device, requires_grad=True)     # alpha = 0 everywhere: 0/0 depth
+    loss, nm, dm = surface_regularizer(am, cam, 0.0, 0.05, 1.0)
+    loss.backward()
+    assert abs(nm.item() - 1.0) < 1e-6 and dm.item() == 0.0
+    assert torch.isfinite(am.grad).all() and float(am.grad[:6].abs().max()) == 0.0
+    np.testing.assert_allclose(am.grad[6].cpu().numpy(), 1.0 / (21 * 37), rtol=1e-6)

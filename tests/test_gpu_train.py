@@ -26,7 +26,7 @@ def test_render_contract_and_loaded_library(gpu_device):
     m, cam, _ = _setup(gpu_device)
     pkg = gaussian_renderer.render(cam, m, PipelineParams(), torch.zeros(3, device=gpu_device))
     assert set(pkg) == {"render", "viewspace_points", "visibility_filter", "radii", "rend_alpha", "rend_normal",
-                        "rend_dist", "surf_depth", "surf_normal"}
+                        "rend_dist", "surf_depth", "surf_normal", "allmap"}
     assert pkg["render"].is_cuda and pkg["render"].shape == (3, 240, 320)
     (pkg["render"].mean() + pkg["rend_dist"].mean()).backward()
     g = pkg["viewspace_points"].grad

@@ -32,7 +32,7 @@ def test_config1_forward_backward_2k_256(oracle_backend):
     pipe, bg = PipelineParams(), torch.zeros(3)
     pkg = gaussian_renderer.render(cam, m, pipe, bg)
     assert set(pkg) == {"render", "viewspace_points", "visibility_filter", "radii", "rend_alpha", "rend_normal",
-                        "rend_dist", "surf_depth", "surf_normal"}
+                        "rend_dist", "surf_depth", "surf_normal", "allmap"}
     assert pkg["render"].shape == (3, 256, 256) and pkg["rend_normal"].shape == (3, 256, 256)
     assert pkg["surf_depth"].shape == (1, 256, 256) and pkg["radii"].dtype == torch.int32
     assert torch.equal(pkg["visibility_filter"], pkg["radii"] > 0)
