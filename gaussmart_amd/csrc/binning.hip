@@ -378,14 +378,28 @@ __global__ void __launch_bounds__(256) finalize_bins_kernel(int D, const uint32_
     if (i == D - 1) ranges[2 * t + 1] = D;
 }
 
+// splat records into (tile, depth) order: 5 threads per instance, one 16-byte piece each
+__global__ void __launch_bounds__(256) gather_stream_kernel(long long n_pieces, const uint32_t* __restrict__ point_list,
+                                                            const float4* __restrict__ splat,
+                                                            float4* __restrict__ stream) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pieces) return;
+    const long long pos = i / 5;
+    const int q = (int)(i - pos * 5);
+    stream[i] = splat[(size_t)point_list[pos] * 5 + q];
+}
+
 int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted, const uint32_t* perm,
-                             const uint32_t* emit_gid, uint32_t* point_list, uint32_t* inst_row,
-                             uint32_t* ranges, hipStream_t s) {
+                             const uint32_t* emit_gid, const float* splat, uint32_t* point_list,
+                             uint32_t* inst_row, uint32_t* ranges, float* stream, hipStream_t s) {
     GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
     if (D <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_FINALIZE, s);
     hipLaunchKernelGGL(finalize_bins_kernel, dim3((D + 255) / 256), dim3(256), 0, s, D, tile_keys_sorted,
                        perm, emit_gid, point_list, inst_row, ranges);
+    const long long n_pieces = (long long)D * 5;
+    hipLaunchKernelGGL(gather_stream_kernel, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, s, n_pieces,
+                       point_list, reinterpret_cast<const float4*>(splat), reinterpret_cast<float4*>(stream));
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

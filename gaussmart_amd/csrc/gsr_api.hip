@@ -214,13 +214,14 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         rc = gsr_radix_sort_pairs(tile_keys, inst_vals, tile_sorted, perm, tk_tmp, tv_tmp, D, 0,
                                   bits_for((uint32_t)n_tiles), sort_ws2, s);
         if (rc != GSR_OK) return rc;
-        rc = gsr_launch_finalize_bins((int)D, n_tiles, tile_sorted, perm, emit_gid, point_list, inst_row, ranges, s);
+        rc = gsr_launch_finalize_bins((int)D, n_tiles, tile_sorted, perm, emit_gid, splat, point_list, inst_row, ranges,
+                                      at<float>(binning, BL.stream), s);
         if (rc != GSR_OK) return rc;
     } else {
         GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
     }
 
-    return gsr_launch_render_fwd(*view, ranges, point_list, splat, at<float>(image, IL.final_T),
+    return gsr_launch_render_fwd(*view, ranges, at<float>(binning, BL.stream), at<float>(image, IL.final_T),
                                  at<uint32_t>(image, IL.n_contrib), out->out_color, out->out_allmap, s);
 }
 
@@ -246,15 +247,20 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     const GsrBinLayout BL(num_rendered, gx * gy);
     const GsrImageLayout IL((int64_t)W * H);
 
-    const size_t rows_bytes = gsr_align(size_t(num_rendered > 0 ? num_rendered : 1) * GSR_GROW_FLOATS * 4);
-    float* grad_rows = static_cast<float*>(alloc(ctx, GSR_BUF_SCRATCH, rows_bytes));
-    if (!grad_rows) { gsr_set_error("allocator returned NULL (gradient rows)"); return GSR_E_ALLOC; }
+    // 4 sub-rows (one per quad) of 80 bytes per instance + one flag byte per sub-row
+    const size_t n_inst = size_t(num_rendered > 0 ? num_rendered : 1);
+    const size_t rows_bytes = gsr_align(n_inst * 4 * GSR_GROW_FLOATS * 4);
+    const size_t flags_bytes = gsr_align(n_inst * 4);
+    char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, rows_bytes + flags_bytes));
+    if (!scratch) { gsr_set_error("allocator returned NULL (gradient rows)"); return GSR_E_ALLOC; }
+    float* grad_rows = reinterpret_cast<float*>(scratch);
+    uint8_t* row_flags = reinterpret_cast<uint8_t*>(scratch + rows_bytes);
 
     if (num_rendered > 0) {
-        rc = gsr_launch_render_bwd(*view, at<uint32_t>(binning, BL.ranges), at<uint32_t>(binning, BL.point_list),
-                                   at<uint32_t>(binning, BL.inst_row), at<float>(geom, GL.splat),
-                                   at<float>(image, IL.final_T), at<uint32_t>(image, IL.n_contrib),
-                                   dL_dcolor, dL_dallmap, grad_rows, s);
+        GSR_HIP_CHECK(hipMemsetAsync(row_flags, 0, size_t(num_rendered) * 4, s));
+        rc = gsr_launch_render_bwd(*view, at<uint32_t>(binning, BL.ranges), at<uint32_t>(binning, BL.inst_row),
+                                   at<float>(binning, BL.stream), at<float>(image, IL.final_T),
+                                   at<uint32_t>(image, IL.n_contrib), dL_dcolor, dL_dallmap, grad_rows, row_flags, s);
         if (rc != GSR_OK) return rc;
     }
     GsrGrads o = *grads;
@@ -264,7 +270,7 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     if (!g->transmat_precomp) o.dL_dtransmat = nullptr;
     return gsr_launch_preprocess_bwd(*view, *g, radii, at<float>(geom, GL.splat), at<uint32_t>(geom, GL.clamped),
                                      at<uint32_t>(geom, GL.tiles_touched), at<uint32_t>(geom, GL.inst_begin),
-                                     grad_rows, o, s);
+                                     grad_rows, reinterpret_cast<const uint32_t*>(row_flags), o, s);
 }
 
 // ------------------------------------------------------------------------------- introspection
@@ -285,6 +291,7 @@ extern "C" int32_t gsr_buffer_field(int32_t which, const char* name, int32_t N, 
         if (!strcmp(name, "point_list")) { *offset = L.point_list; *bytes = size_t(D) * 4; return GSR_OK; }
         if (!strcmp(name, "inst_row")) { *offset = L.inst_row; *bytes = size_t(D) * 4; return GSR_OK; }
         if (!strcmp(name, "ranges")) { *offset = L.ranges; *bytes = size_t(gx) * gy * 8; return GSR_OK; }
+        if (!strcmp(name, "stream")) { *offset = L.stream; *bytes = size_t(D) * GSR_SPLAT_FLOATS * 4; return GSR_OK; }
     } else if (which == GSR_BUF_IMAGE) {
         const GsrImageLayout L(P);
         if (!strcmp(name, "final_T")) { *offset = L.final_T; *bytes = size_t(P) * 12; return GSR_OK; }

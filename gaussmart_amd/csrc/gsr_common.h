@@ -49,8 +49,10 @@ struct GsrProfileScope {
 #define GSR_SP_RGB 15
 #define GSR_SP_RECT 18   // two 32-bit words: (x0 | x1 << 16), (y0 | y1 << 16), signed 16-bit each
 
-// One gradient row per (Gaussian, tile) instance, written by render_bwd, summed by
-// preprocess_bwd: [dTu.xyz dTv.xyz dTw.xyz | dxy | dn.xyz | dopa | drgb | pad pad]
+// One gradient row per (Gaussian, tile, 8x8 quad) = 4 sub-rows per instance, written by render_bwd
+// (each wave64 owns one quad and writes its own sub-row: no cross-wave combine, no atomics) and
+// summed by preprocess_bwd; a byte flag per sub-row says whether it was written at all:
+// [dTu.xyz dTv.xyz dTw.xyz | dxy | dn.xyz | dopa | drgb | pad pad]
 #define GSR_GROW_FLOATS 20
 #define GSR_GR_T 0
 #define GSR_GR_XY 9
@@ -73,12 +75,15 @@ struct GsrGeomLayout {
     }
 };
 struct GsrBinLayout {
-    size_t point_list, inst_row, ranges, total;
+    size_t point_list, inst_row, ranges, stream, total;
     GsrBinLayout(int64_t D, int64_t tiles) {
         size_t o = 0;
         point_list = o; o += gsr_align(size_t(D) * 4);
         inst_row = o;   o += gsr_align(size_t(D) * 4);
         ranges = o;     o += gsr_align(size_t(tiles) * 8);
+        // splat records copied into (tile, depth) order: the render kernels stream them with
+        // coalesced loads instead of gathering 80-byte records by Gaussian id twice per iteration
+        stream = o;     o += gsr_align(size_t(D) * GSR_SPLAT_FLOATS * 4);
         total = o > 0 ? o : 256;
     }
 };
@@ -112,19 +117,21 @@ int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const 
                     uint32_t* inst_begin, uint32_t* tile_keys, uint32_t* inst_vals,
                     uint32_t* emit_gid, hipStream_t s);
 int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted,
-                             const uint32_t* perm, const uint32_t* emit_gid, uint32_t* point_list,
-                             uint32_t* inst_row, uint32_t* ranges, hipStream_t s);
-int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const uint32_t* point_list,
-                          const float* splat, float* final_T, uint32_t* n_contrib,
-                          float* out_color, float* out_allmap, hipStream_t s);
-int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* point_list,
-                          const uint32_t* inst_row, const float* splat, const float* final_T,
-                          const uint32_t* n_contrib, const float* dL_dcolor,
-                          const float* dL_dallmap, float* grad_rows, hipStream_t s);
+                             const uint32_t* perm, const uint32_t* emit_gid, const float* splat,
+                             uint32_t* point_list, uint32_t* inst_row, uint32_t* ranges,
+                             float* stream, hipStream_t s);
+int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* stream,
+                          float* final_T, uint32_t* n_contrib, float* out_color,
+                          float* out_allmap, hipStream_t s);
+int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* inst_row,
+                          const float* stream, const float* final_T, const uint32_t* n_contrib,
+                          const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
+                          uint8_t* row_flags, hipStream_t s);
 int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int32_t* radii,
                               const float* splat, const uint32_t* clamped,
                               const uint32_t* tiles_touched, const uint32_t* inst_begin,
-                              const float* grad_rows, const GsrGrads& out, hipStream_t s);
+                              const float* grad_rows, const uint32_t* row_flags,
+                              const GsrGrads& out, hipStream_t s);
 
 // ---------------------------------------------------------------- small device helpers
 #ifdef __HIPCC__

@@ -1,5 +1,6 @@
 // K8 preprocess_bwd: one thread per Gaussian.
-//   1. sum this Gaussian's per-instance gradient rows (contiguous: rows are in emission order),
+//   1. sum this Gaussian's flagged per-(instance, quad) gradient sub-rows (contiguous: rows are in
+//      emission order) in a fixed order,
 //   2. densification statistic for means2D.grad (consumer scene/gaussian_model.py:551-553),
 //   3. chain rule  AABB centre -> T,  T -> (mean3D, scale, quaternion),  normal -> quaternion,
 //   4. SH backward (clamp mask, view-direction term into mean3D).
@@ -19,7 +20,7 @@ struct PreBwdParams {
     const float* means; const float* shs; const float* scales; const float* rots;
     const float* tprecomp;
     const int32_t* radii; const float* splat; const uint32_t* clamped;
-    const uint32_t* tiles; const uint32_t* inst_begin; const float* grad_rows;
+    const uint32_t* tiles; const uint32_t* inst_begin; const float* grad_rows; const uint32_t* row_flags;
     GsrGrads out;
 };
 
@@ -65,12 +66,19 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
         float acc[20];
 #pragma unroll
         for (int k = 0; k < 20; ++k) acc[k] = 0.f;
-        const float4* rows = reinterpret_cast<const float4*>(p.grad_rows + (size_t)b * GSR_GROW_FLOATS);
+        // 4 sub-rows per instance (one per 8x8 quad of the tile); only the flagged ones were written
+        const float4* rows = reinterpret_cast<const float4*>(p.grad_rows + (size_t)b * 4 * GSR_GROW_FLOATS);
         for (uint32_t e = 0; e < cnt; ++e) {
+            const uint32_t f = p.row_flags[b + e];       // 4 byte flags
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const float4 v = rows[(size_t)e * 5 + q];
-                acc[4 * q + 0] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+            for (int sub = 0; sub < 4; ++sub) {
+                if ((f >> (8 * sub)) & 0xFFu) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        const float4 v = rows[((size_t)e * 4 + sub) * 5 + q];
+                        acc[4 * q + 0] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+                    }
+                }
             }
         }
 #pragma unroll
@@ -289,14 +297,15 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
 int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int32_t* radii,
                               const float* splat, const uint32_t* clamped,
                               const uint32_t* tiles_touched, const uint32_t* inst_begin,
-                              const float* grad_rows, const GsrGrads& out, hipStream_t s) {
+                              const float* grad_rows, const uint32_t* row_flags, const GsrGrads& out,
+                              hipStream_t s) {
     if (g.count <= 0) return GSR_OK;
     PreBwdParams p;
     p.N = g.count; p.W = v.width; p.H = v.height; p.deg = v.sh_degree; p.M = v.sh_coeffs;
     p.mod = v.scale_modifier; p.view = v.viewmatrix; p.proj = v.projmatrix; p.campos = v.campos;
     p.means = g.means3D; p.shs = g.shs; p.scales = g.scales; p.rots = g.rotations;
     p.tprecomp = g.transmat_precomp; p.radii = radii; p.splat = splat; p.clamped = clamped;
-    p.tiles = tiles_touched; p.inst_begin = inst_begin; p.grad_rows = grad_rows; p.out = out;
+    p.tiles = tiles_touched; p.inst_begin = inst_begin; p.grad_rows = grad_rows; p.row_flags = row_flags; p.out = out;
     const int blocks = (g.count + PB_BLOCK - 1) / PB_BLOCK;
     GsrProfileScope prof(GSR_K_PREPROCESS_BWD, s);
     const bool stage = g.shs != nullptr && v.sh_coeffs * 3 <= 48 && (v.sh_coeffs * 3) % 4 == 0 &&

@@ -1,37 +1,50 @@
-// K7 render_bwd: back-to-front replay of every tile, producing ONE gradient row per
-// (Gaussian, tile) instance -- no floating-point atomics anywhere.
+// K7 render_bwd: back-to-front replay of every tile -- no floating-point atomics anywhere.
 //
 // Restates the [U]/[P] backward of the surfel compositing (colour, expected depth, alpha, normal,
 // median depth, distortion), see DESIGN.md section "render_bwd" for the recursion; it is the exact
 // derivative of render_fwd except for the two flagged quirks (GSR_FLAG_*).
 //
-// MI355X mapping
-//   * same pixel mapping as the forward: 4 wave64s x (8x8 pixel quad);
-//   * per (wave, splat) the 18 partial derivatives are summed over the wave's 64 pixels with DPP
-//     row operations (4 in-row butterflies + row_bcast15 + row_bcast31: 6 VALU per value) and only
-//     if some lane of the wave actually touched the splat;
-//   * each wave deposits its sums in its OWN LDS slot; after a batch the workgroup adds the (at
-//     most 4) slots in fixed wave order and stores the 80-byte row of that instance with plain
-//     16-byte stores.  Summation order is fixed => bitwise reproducible gradients, and the HBM
-//     side sees streaming stores instead of ~18 atomics per pixel-splat pair.
-//   * rows are indexed by emission order (inst_row), so preprocess_bwd reads each Gaussian's rows
-//     as one contiguous segment.
+// MI355X mapping: WAVE-INDEPENDENT, like the forward.  Each wave64 of a tile's workgroup owns an 8x8
+// pixel quad and never synchronises with the other three:
+//   * it starts at the deepest list entry ANY OF ITS 64 PIXELS reached (quad-level, not tile-level)
+//     and streams the (tile, depth)-ordered splat records backwards, 64 per batch, coalesced, into
+//     its private LDS slice while the next batch is prefetched into registers;
+//   * a 64-bit ballot of "cull rect overlaps my quad" selects the splats it evaluates at all;
+//   * the suffix recursions of colour, depth, alpha and normal are collapsed into ONE scalar
+//     recursion (they are linear: q_i = c_i.dL/dC + z_i dL/dD + dL/dA + n_i.dL/dN);
+//   * the 18 partial derivatives are summed over the 64 pixels with the transposed butterfly below
+//     (gfx950 v_permlane32_swap / v_permlane16_swap + DPP, ~50 VALU) and land distributed over the
+//     lanes, which store them straight into the wave's OWN 80-byte sub-row of that instance
+//     (4 sub-rows per instance, one per quad) plus a 1-byte "written" flag;
+//   * preprocess_bwd adds the flagged sub-rows in fixed order => bitwise reproducible gradients, and
+//     HBM sees plain streaming stores instead of ~18 atomics per pixel-splat pair.
 #include "gsr_common.h"
 #include "pair_eval.h"
 
+// five coalesced 16-byte loads per lane = 64 records of 80 bytes; pieces beyond `lim` read as zero
+#define GSR_LOAD5(ptr, lim)                                            \
+    do {                                                               \
+        const int lim_ = (lim);                                        \
+        pf0 = zero4; pf1 = zero4; pf2 = zero4; pf3 = zero4; pf4 = zero4; \
+        if (lane < lim_) pf0 = (ptr)[lane];                            \
+        if (64 + lane < lim_) pf1 = (ptr)[64 + lane];                  \
+        if (128 + lane < lim_) pf2 = (ptr)[128 + lane];                \
+        if (192 + lane < lim_) pf3 = (ptr)[192 + lane];                \
+        if (256 + lane < lim_) pf4 = (ptr)[256 + lane];                \
+    } while (0)
+
 #define RB_BLOCK 256
 #define RB_WAVES 4
-#define RB_BATCH 64
 #define RB_ROW GSR_GROW_FLOATS   // 20 floats
 
 struct RenderBwdParams {
     int W, H, gx;
     uint32_t flags;
-    const uint32_t* ranges; const uint32_t* point_list; const uint32_t* inst_row;
-    const float* splat; const float* bg;
+    const uint32_t* ranges; const uint32_t* inst_row;
+    const float4* stream; const float* bg;
     const float* final_T; const uint32_t* n_contrib;
     const float* dL_dcolor; const float* dL_dallmap;
-    float* grad_rows;
+    float* grad_rows; uint8_t* row_flags;
 };
 
 // ---- wave64 reductions -----------------------------------------------------------------------------
@@ -85,38 +98,39 @@ __device__ __forceinline__ float wave_sum2(float a, float b) {
 }
 
 __global__ void __launch_bounds__(RB_BLOCK) render_bwd_kernel(RenderBwdParams p) {
-    __shared__ float4 s_rec[RB_BATCH * 5];
-    __shared__ __attribute__((aligned(16))) float s_acc[RB_WAVES][RB_BATCH][RB_ROW];
-    __shared__ unsigned long long s_touched[RB_WAVES];
-    __shared__ uint32_t s_row[RB_BATCH];
-    __shared__ uint32_t s_max_contrib;
+    __shared__ float4 s_rec_all[RB_WAVES][64 * 5];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    float4* s_rec = s_rec_all[wave];
     const int tile_x = blockIdx.x, tile_y = blockIdx.y;
-    const int pxi = tile_x * GSR_TILE + (wave & 1) * 8 + (lane & 7);
-    const int pyi = tile_y * GSR_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
+    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
     const bool inside = pxi < p.W && pyi < p.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
     const int pix_id = pyi * p.W + pxi;
     const int HW = p.W * p.H;
 
     const uint32_t tile = (uint32_t)(tile_y * p.gx + tile_x);
-    const uint32_t r0 = p.ranges[2 * tile], r1 = p.ranges[2 * tile + 1];
-    const int n_list = (int)(r1 - r0);
-    if (n_list == 0) return;
+    const uint32_t r0 = p.ranges[2 * tile];
+
+    // the deepest list entry any pixel of THIS QUAD reached
+    const int last_contributor = inside ? (int)p.n_contrib[pix_id] : 0;
+    int max_contrib = last_contributor;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) max_contrib = max(max_contrib, __shfl_xor(max_contrib, d, 64));
+    max_contrib = __builtin_amdgcn_readfirstlane(max_contrib);
+    if (max_contrib == 0) return;
 
     const bool clamp_pass = (p.flags & GSR_FLAG_CLAMP_PASSTHROUGH) != 0;
     const bool filter_depth_quirk = (p.flags & GSR_FLAG_FILTER_DEPTH_GRAD) != 0;
     const bool no_cull = (p.flags & (uint32_t)GSR_FLAG_DEBUG_NO_CULL) != 0;
-    const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
 
     // per-pixel state saved by the forward
     const float T_final = inside ? p.final_T[pix_id] : 0.f;
     const float final_D = inside ? p.final_T[pix_id + HW] : 0.f;       // sum m w
     const float final_D2 = inside ? p.final_T[pix_id + 2 * HW] : 0.f;  // sum m^2 w
     const float final_A = 1.0f - T_final;
-    const int last_contributor = inside ? (int)p.n_contrib[pix_id] : 0;
     const int median_contributor = inside ? (int)p.n_contrib[pix_id + HW] : 0;
 
     float dL_dpix0 = 0.f, dL_dpix1 = 0.f, dL_dpix2 = 0.f;
@@ -134,48 +148,34 @@ __global__ void __launch_bounds__(RB_BLOCK) render_bwd_kernel(RenderBwdParams p)
     }
     const float bg_dot_dpixel = p.bg[0] * dL_dpix0 + p.bg[1] * dL_dpix1 + p.bg[2] * dL_dpix2;
 
-    // the deepest list entry any pixel of the tile reached
-    if (tid == 0) s_max_contrib = 0;
-    __syncthreads();
-    {
-        int m = last_contributor;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
-        if (lane == 0) atomicMax(&s_max_contrib, (uint32_t)m);
-    }
-    __syncthreads();
-    const int max_contrib = (int)s_max_contrib;
-
-    // rows of instances nobody reached are zero
-    for (int i = max_contrib + tid; i < n_list; i += RB_BLOCK) {
-        float4* row = reinterpret_cast<float4*>(p.grad_rows + (size_t)p.inst_row[r0 + i] * RB_ROW);
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int q = 0; q < RB_ROW / 4; ++q) row[q] = z;
-    }
-
     // running state of the back-to-front recursion
     float T = T_final;
-    float last_alpha = 0.f;
-    float last_c0 = 0.f, last_c1 = 0.f, last_c2 = 0.f, acc_c0 = 0.f, acc_c1 = 0.f, acc_c2 = 0.f;
-    float last_depth = 0.f, acc_depth = 0.f, acc_alpha = 0.f;
-    float last_n0 = 0.f, last_n1 = 0.f, last_n2 = 0.f, acc_n0 = 0.f, acc_n1 = 0.f, acc_n2 = 0.f;
-    float last_dL_dT = 0.f;
+    float last_alpha = 0.f, last_q = 0.f, acc_q = 0.f, last_dL_dT = 0.f;
 
-    for (int hi = max_contrib; hi > 0; hi -= RB_BATCH) {
-        const int nb = min(RB_BATCH, hi);
-        __syncthreads();   // previous batch fully flushed before LDS is reused
-        if (tid < nb) {
-            const int li = hi - 1 - tid;            // list index of staged entry `tid`
-            const uint32_t gid = p.point_list[r0 + li];
-            s_row[tid] = p.inst_row[r0 + li];
-            const float4* src = reinterpret_cast<const float4*>(p.splat + (size_t)gid * GSR_SPLAT_FLOATS);
-#pragma unroll
-            for (int q = 0; q < 5; ++q) s_rec[tid * 5 + q] = src[q];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pf0, pf1, pf2, pf3, pf4;   // named (not an array): keeps the prefetch in VGPRs, not scratch
+    uint32_t pf_row = 0;
+    int hi = max_contrib;
+    {
+        const int lo = max(0, hi - 64), cnt = hi - lo;
+        const float4* src = p.stream + (size_t)(r0 + lo) * 5;
+GSR_LOAD5(src, cnt * 5);
+        pf_row = lane < cnt ? p.inst_row[r0 + lo + lane] : 0u;
+    }
+
+    while (hi > 0) {
+        const int lo = max(0, hi - 64), nb = hi - lo;
+s_rec[lane] = pf0; s_rec[64 + lane] = pf1; s_rec[128 + lane] = pf2; s_rec[192 + lane] = pf3; s_rec[256 + lane] = pf4;
+        const uint32_t row_of_lane = pf_row;          // emission index of staged entry `lane`
+        {   // prefetch the next (shallower) batch
+            const int hi2 = lo, lo2 = max(0, hi2 - 64), cnt = hi2 - lo2;
+            const float4* src = p.stream + (size_t)(r0 + lo2) * 5;
+GSR_LOAD5(src, cnt * 5);
+            pf_row = lane < cnt ? p.inst_row[r0 + lo2 + lane] : 0u;
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 
-        unsigned long long touched = 0ull;
         // which staged splats can reach alpha >= 1/255 inside this wave's 8x8 quad at all?
         bool ov = false;
         if (lane < nb) {
@@ -184,16 +184,15 @@ __global__ void __launch_bounds__(RB_BLOCK) render_bwd_kernel(RenderBwdParams p)
         }
         unsigned long long todo_mask = __ballot(ov);
         while (todo_mask) {
-            const int j = __builtin_ctzll(todo_mask);
-            todo_mask &= todo_mask - 1;
-            const int cidx = hi - 1 - j;            // 0-based position in the tile list
+            const int j = 63 - __builtin_clzll(todo_mask);      // deepest first
+            todo_mask &= ~(1ull << j);
+            const int cidx = lo + j;                            // 0-based position in the tile list
             const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
             const float4 a3 = s_rec[j * 5 + 3];
             GsrPair pr;
             bool active = cidx < last_contributor;
             if (active) active = gsr_pair_eval(pxf, pyf, a0, a1, a2, a3.z, pr);
             if (!__any(active)) continue;           // whole wave untouched by this splat
-            touched |= 1ull << j;
 
             float gT[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float gxy0 = 0.f, gxy1 = 0.f, gn0 = 0.f, gn1 = 0.f, gn2 = 0.f, gopa = 0.f;
@@ -202,53 +201,41 @@ __global__ void __launch_bounds__(RB_BLOCK) render_bwd_kernel(RenderBwdParams p)
                 const float4 a4 = s_rec[j * 5 + 4];
                 const float alpha = pr.alpha, G = pr.G, c_d = pr.depth;
                 const float one_m_alpha = 1.0f - alpha;
-                T = T * gsr_rcp(one_m_alpha);
+                const float inv_oma = gsr_rcp(one_m_alpha);
+                T = T * inv_oma;
                 const float w = alpha * T;
 
-                float dL_dalpha = 0.f;
-                // colour
+                // colour, expected depth, alpha and normal share one suffix recursion:
+                //   q_i = c_i . dL/dC + z_i dL/dD + 1 dL/dA + n_i . dL/dN
                 const float c0 = a3.w, c1 = a4.x, c2 = a4.y;
-                acc_c0 = last_alpha * last_c0 + (1.f - last_alpha) * acc_c0; last_c0 = c0;
-                acc_c1 = last_alpha * last_c1 + (1.f - last_alpha) * acc_c1; last_c1 = c1;
-                acc_c2 = last_alpha * last_c2 + (1.f - last_alpha) * acc_c2; last_c2 = c2;
-                dL_dalpha += (c0 - acc_c0) * dL_dpix0 + (c1 - acc_c1) * dL_dpix1 + (c2 - acc_c2) * dL_dpix2;
+                const float n0 = a2.w, n1 = a3.x, n2 = a3.y;
+                const float q = c0 * dL_dpix0 + c1 * dL_dpix1 + c2 * dL_dpix2 + c_d * dL_ddepth + dL_daccum
+                              + n0 * dL_dn0 + n1 * dL_dn1 + n2 * dL_dn2;
+                acc_q = last_alpha * last_q + (1.f - last_alpha) * acc_q;
+                last_q = q;
+                float dL_dalpha = q - acc_q;
                 gc0 = w * dL_dpix0; gc1 = w * dL_dpix1; gc2 = w * dL_dpix2;
+                gn0 = w * dL_dn0; gn1 = w * dL_dn1; gn2 = w * dL_dn2;
 
                 // distortion, median depth
                 float dmd_dd;
                 const float m_d = gsr_depth_map(c_d, dmd_dd);
-                float dL_dz = 0.f;
+                float dL_dz = w * dL_ddepth;
                 if (cidx == median_contributor - 1) dL_dz += dL_dmedian;
                 const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
                 dL_dalpha += dL_dweight - last_dL_dT;
                 last_dL_dT = dL_dweight * alpha + one_m_alpha * last_dL_dT;
-                const float dL_dmd = 2.0f * w * (m_d * final_A - final_D) * dL_dreg;
-                dL_dz += dL_dmd * dmd_dd;
-
-                // expected depth, alpha
-                acc_depth = last_alpha * last_depth + (1.f - last_alpha) * acc_depth; last_depth = c_d;
-                dL_dalpha += (c_d - acc_depth) * dL_ddepth;
-                acc_alpha = last_alpha + (1.f - last_alpha) * acc_alpha;
-                dL_dalpha += (1.f - acc_alpha) * dL_daccum;
-
-                // normal
-                const float n0 = a2.w, n1 = a3.x, n2 = a3.y;
-                acc_n0 = last_alpha * last_n0 + (1.f - last_alpha) * acc_n0; last_n0 = n0;
-                acc_n1 = last_alpha * last_n1 + (1.f - last_alpha) * acc_n1; last_n1 = n1;
-                acc_n2 = last_alpha * last_n2 + (1.f - last_alpha) * acc_n2; last_n2 = n2;
-                dL_dalpha += (n0 - acc_n0) * dL_dn0 + (n1 - acc_n1) * dL_dn1 + (n2 - acc_n2) * dL_dn2;
-                gn0 = w * dL_dn0; gn1 = w * dL_dn1; gn2 = w * dL_dn2;
+                dL_dz += 2.0f * w * (m_d * final_A - final_D) * dL_dreg * dmd_dd;
 
                 dL_dalpha *= T;
                 last_alpha = alpha;
                 // alpha also scales how much background shows through
-                dL_dalpha += (-T_final * gsr_rcp(one_m_alpha)) * bg_dot_dpixel;
+                dL_dalpha -= T_final * inv_oma * bg_dot_dpixel;
 
                 // alpha = min(0.99, opa * G)
                 const float dL_daraw = (clamp_pass || pr.araw <= GSR_ALPHA_MAX) ? dL_dalpha : 0.f;
                 const float dL_dG = a3.z * dL_daraw;
                 gopa = G * dL_daraw;
-                dL_dz += w * dL_ddepth;
 
                 const float Twx = a1.z, Twy = a1.w;
                 if (pr.use3d) {
@@ -272,58 +259,37 @@ __global__ void __launch_bounds__(RB_BLOCK) render_bwd_kernel(RenderBwdParams p)
                 }
             }
 
-            // wave-level sums -> this wave's LDS slot (row layout GSR_GR_*)
+            // wave-level sums, stored by the lanes that end up holding them (row layout GSR_GR_*)
             {
                 const float v16[16] = {gT[0], gT[1], gT[2], gT[3], gT[4], gT[5], gT[6], gT[7], gT[8],
                                        gn0, gn1, gn2, gopa, gc0, gc1, gc2};
                 const float tot = wave_sum16_transposed(v16, lane);
                 const float xy = wave_sum2(gxy0, gxy1);
-                float* slot = &s_acc[wave][j][0];
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)row_of_lane, j);
+                float* row = p.grad_rows + ((size_t)e * 4 + wave) * RB_ROW;
                 const int vi = lane >> 2;
-                if ((lane & 3) == 0) slot[vi < 9 ? vi : vi + 2] = tot;      // skip the two xy columns
-                if (lane == 16) slot[GSR_GR_XY] = xy;
-                if (lane == 48) slot[GSR_GR_XY + 1] = xy;
+                if ((lane & 3) == 0) row[vi < 9 ? vi : vi + 2] = tot;      // skip the two xy columns
+                if (lane == 16) row[GSR_GR_XY] = xy;
+                if (lane == 48) row[GSR_GR_XY + 1] = xy;
+                if (lane == 0) p.row_flags[(size_t)e * 4 + wave] = 1;
             }
         }
-        if (lane == 0) s_touched[wave] = touched;
-        __syncthreads();
-
-        // flush: 4 threads per instance, 5 floats each... one float4-sized piece (+1) per thread
-        // layout: thread t -> instance j = t >> 2, piece q = t & 3 handles float4 q, and q==0 also float4 4
-        {
-            const int j = tid >> 2, q = tid & 3;
-            if (j < nb) {
-                float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-#pragma unroll
-                for (int w = 0; w < RB_WAVES; ++w) {
-                    if ((s_touched[w] >> j) & 1ull) {
-                        const float4 v = *reinterpret_cast<const float4*>(&s_acc[w][j][4 * q]);
-                        s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
-                        if (q == 0) {
-                            const float4 u = *reinterpret_cast<const float4*>(&s_acc[w][j][16]);
-                            s1.x += u.x; s1.y += u.y; s1.z += u.z; s1.w += u.w;
-                        }
-                    }
-                }
-                float4* row = reinterpret_cast<float4*>(p.grad_rows + (size_t)s_row[j] * RB_ROW);
-                row[q] = s0;
-                if (q == 0) row[4] = s1;
-            }
-        }
+        __builtin_amdgcn_wave_barrier();   // all reads of this batch precede the next batch's LDS writes
+        hi = lo;
     }
 }
 
-int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* point_list,
-                          const uint32_t* inst_row, const float* splat, const float* final_T,
-                          const uint32_t* n_contrib, const float* dL_dcolor,
-                          const float* dL_dallmap, float* grad_rows, hipStream_t s) {
+int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* inst_row,
+                          const float* stream, const float* final_T, const uint32_t* n_contrib,
+                          const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
+                          uint8_t* row_flags, hipStream_t s) {
     RenderBwdParams p;
     p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
     p.flags = v.flags;
-    p.ranges = ranges; p.point_list = point_list; p.inst_row = inst_row; p.splat = splat; p.bg = v.bg;
+    p.ranges = ranges; p.inst_row = inst_row; p.stream = reinterpret_cast<const float4*>(stream); p.bg = v.bg;
     p.final_T = final_T; p.n_contrib = n_contrib; p.dL_dcolor = dL_dcolor; p.dL_dallmap = dL_dallmap;
-    p.grad_rows = grad_rows;
+    p.grad_rows = grad_rows; p.row_flags = row_flags;
     if (p.gx <= 0 || gy <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_RENDER_BWD, s);
     hipLaunchKernelGGL(render_bwd_kernel, dim3(p.gx, gy), dim3(RB_BLOCK), 0, s, p);

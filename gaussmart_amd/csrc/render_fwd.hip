@@ -1,109 +1,128 @@
-// K6 render_fwd: one 256-thread workgroup per 16x16 tile, front-to-back alpha compositing of
-// 2D-Gaussian surfels with the depth / normal / median-depth / distortion side outputs.
-// Restates the [U] forward render; output channel order pinned by
-// gaussian_renderer/__init__.py:117-141 (allmap = depth, alpha, normal xyz, median depth, dist).
+// K6 render_fwd: front-to-back alpha compositing of 2D-Gaussian surfels with the depth / normal /
+// median-depth / distortion side outputs.  Restates the [U] forward render; output channel order
+// pinned by gaussian_renderer/__init__.py:117-141 (allmap = depth, alpha, normal xyz, median, dist).
 //
-// MI355X mapping: the tile's 4 wave64s each own an 8x8 pixel quad (compact footprint => a small
-// splat touches few waves and whole-wave skips are common).  Per round the workgroup gathers up to
-// 256 splat records (80 B, five 16-byte loads per thread) into LDS; the inner loop reads them with
-// wave-uniform (broadcast) ds_read_b128.  Per 64 staged splats each lane tests ONE splat's cull rect
-// against the wave's quad and a 64-bit ballot becomes the list of splats the wave has to look at at
-// all (s_ff1 iteration): splats that cannot reach alpha >= 1/255 in the quad cost nothing.  A wave
-// whose 64 pixels are all done leaves the round; the workgroup leaves once every pixel is done.
+// MI355X mapping: WAVE-INDEPENDENT.  A 16x16 tile is still one 256-thread workgroup (tile keys stay
+// those of the reference), but its four wave64s each own an 8x8 pixel quad and never synchronise
+// with each other -- no workgroup barrier anywhere:
+//   * a wave streams the tile's splat records (already in (tile, depth) order, see binning.hip)
+//     64 at a time with five coalesced 16-byte loads per lane into its PRIVATE 5 KiB LDS slice, the
+//     next 64 being prefetched into registers while the current ones are composited;
+//   * each lane tests ONE staged splat's cull rect against the wave's quad; the 64-bit ballot is the
+//     list of splats the wave has to look at at all (iterated with s_ff1), the rest cost nothing;
+//   * per surviving splat the record is read with wave-uniform (broadcast) ds_read_b128;
+//   * the wave leaves as soon as ITS 64 pixels are done (quad-level early termination).
 #include "gsr_common.h"
 #include "pair_eval.h"
 
+// five coalesced 16-byte loads per lane = 64 records of 80 bytes; pieces beyond `lim` read as zero
+#define GSR_LOAD5(ptr, lim)                                            \
+    do {                                                               \
+        const int lim_ = (lim);                                        \
+        pf0 = zero4; pf1 = zero4; pf2 = zero4; pf3 = zero4; pf4 = zero4; \
+        if (lane < lim_) pf0 = (ptr)[lane];                            \
+        if (64 + lane < lim_) pf1 = (ptr)[64 + lane];                  \
+        if (128 + lane < lim_) pf2 = (ptr)[128 + lane];                \
+        if (192 + lane < lim_) pf3 = (ptr)[192 + lane];                \
+        if (256 + lane < lim_) pf4 = (ptr)[256 + lane];                \
+    } while (0)
+
 #define RF_BLOCK 256
-#define RF_BATCH 256
+#define RF_WAVES 4
 
 struct RenderFwdParams {
     int W, H, gx;
     uint32_t flags;
-    const uint32_t* ranges; const uint32_t* point_list; const float* splat;
+    const uint32_t* ranges; const float4* stream;
     const float* bg;
     float* final_T; uint32_t* n_contrib; float* out_color; float* out_allmap;
 };
 
 __global__ void __launch_bounds__(RF_BLOCK) render_fwd_kernel(RenderFwdParams p) {
-    __shared__ float4 s_rec[RF_BATCH * 5];
+    __shared__ float4 s_rec_all[RF_WAVES][64 * 5];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    float4* s_rec = s_rec_all[wave];
     const int tile_x = blockIdx.x, tile_y = blockIdx.y;
-    const int pxi = tile_x * GSR_TILE + (wave & 1) * 8 + (lane & 7);
-    const int pyi = tile_y * GSR_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
+    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
     const bool inside = pxi < p.W && pyi < p.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
     const int pix_id = pyi * p.W + pxi;
     const int HW = p.W * p.H;
+    const bool no_cull = (p.flags & (uint32_t)GSR_FLAG_DEBUG_NO_CULL) != 0;
 
     const uint32_t tile = (uint32_t)(tile_y * p.gx + tile_x);
     const uint32_t r0 = p.ranges[2 * tile], r1 = p.ranges[2 * tile + 1];
-    int todo = (int)(r1 - r0);
-    const int rounds = (todo + RF_BATCH - 1) / RF_BATCH;
+    const int n_list = (int)(r1 - r0);
 
     bool done = !inside;
     float T = 1.0f;
     uint32_t last_contributor = 0;
-    const bool no_cull = (p.flags & (uint32_t)GSR_FLAG_DEBUG_NO_CULL) != 0;
-    const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
     float N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float Dacc = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med_depth = 0.f;
     uint32_t med_contrib = 0xFFFFFFFFu;   // "-1" stored in the u32 plane, as recalled
 
-    for (int rd = 0; rd < rounds; ++rd, todo -= RF_BATCH) {
-        if (__syncthreads_and(done)) break;
-        const int progress = rd * RF_BATCH + tid;
-        if (r0 + progress < r1) {
-            const uint32_t gid = p.point_list[r0 + progress];
-            const float4* src = reinterpret_cast<const float4*>(p.splat + (size_t)gid * GSR_SPLAT_FLOATS);
-#pragma unroll
-            for (int q = 0; q < 5; ++q) s_rec[tid * 5 + q] = src[q];
+    // records of one batch are 64*5 consecutive float4: lane l fetches pieces l, l+64, ... (coalesced)
+    const float4* src = p.stream + (size_t)r0 * 5;
+    float4 pf0, pf1, pf2, pf3, pf4;   // named (not an array): keeps the prefetch in VGPRs, not scratch
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const int lim = min(64, n_list) * 5;
+GSR_LOAD5(src, lim);
+    }
+
+    for (int base = 0; base < n_list; base += 64) {
+        if (__all(done)) break;
+        const int nb = min(64, n_list - base);
+s_rec[lane] = pf0; s_rec[64 + lane] = pf1; s_rec[128 + lane] = pf2; s_rec[192 + lane] = pf3; s_rec[256 + lane] = pf4;
+        {   // prefetch the next batch while this one is composited
+            const int nxt = base + 64;
+            const int lim = nxt < n_list ? min(64, n_list - nxt) * 5 : 0;
+            const float4* s2 = src + (size_t)nxt * 5;
+GSR_LOAD5(s2, lim);
         }
-        __syncthreads();
-        const int nb = min(RF_BATCH, todo);
-        bool wave_done = false;
-        for (int jbase = 0; jbase < nb && !wave_done; jbase += 64) {
-            // one ballot per 64 staged splats: which of them can reach alpha >= 1/255 inside this
-            // wave's 8x8 pixel quad at all (conservative cull rect from preprocess_fwd)?
-            const int jj = jbase + lane;
-            bool ov = false;
-            if (jj < nb) {
-                const float4 r4 = s_rec[jj * 5 + 4];
-                ov = no_cull || gsr_rect_overlaps_quad(__float_as_uint(r4.z), __float_as_uint(r4.w), qx0, qy0);
-            }
-            unsigned long long m = __ballot(ov);
-            while (m) {
-                // every lane is active here (the loop is wave-uniform), so the vote sees the whole wave
-                if (__all(done)) { wave_done = true; break; }
-                const int j = jbase + __builtin_ctzll(m);
-                m &= m - 1;
-                if (done) continue;
-                const uint32_t contributor = (uint32_t)(rd * RF_BATCH + j + 1);   // 1-based list position
-                const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
-                const float4 a3 = s_rec[j * 5 + 3];
-                GsrPair pr;
-                if (!gsr_pair_eval(pxf, pyf, a0, a1, a2, a3.z, pr)) continue;
-                const float alpha = pr.alpha, depth = pr.depth;
-                const float test_T = T * (1.0f - alpha);
-                if (test_T < GSR_T_EPS) { done = true; continue; }
-                const float4 a4 = s_rec[j * 5 + 4];
-                const float w = alpha * T;
-                const float A = 1.0f - T;
-                float dm_dz_unused;
-                const float m_d = gsr_depth_map(depth, dm_dz_unused);
-                dist += (m_d * m_d * A + M2 - 2.0f * m_d * M1) * w;
-                Dacc += depth * w;
-                M1 += m_d * w;
-                M2 += m_d * m_d * w;
-                if (T > 0.5f) { med_depth = depth; med_contrib = contributor; }
-                N0 += a2.w * w; N1 += a3.x * w; N2 += a3.y * w;
-                C0 += a3.w * w; C1 += a4.x * w; C2 += a4.y * w;
-                T = test_T;
-                last_contributor = contributor;
-            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        bool ov = false;
+        if (lane < nb) {
+            const float4 r4 = s_rec[lane * 5 + 4];
+            ov = no_cull || gsr_rect_overlaps_quad(__float_as_uint(r4.z), __float_as_uint(r4.w), qx0, qy0);
         }
+        unsigned long long m = __ballot(ov);
+        while (m) {
+            // every lane is active here (the loop is wave-uniform), so the vote sees the whole wave
+            if (__all(done)) break;
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            if (done) continue;
+            const uint32_t contributor = (uint32_t)(base + j + 1);   // 1-based position in the tile list
+            const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
+            const float4 a3 = s_rec[j * 5 + 3];
+            GsrPair pr;
+            if (!gsr_pair_eval(pxf, pyf, a0, a1, a2, a3.z, pr)) continue;
+            const float alpha = pr.alpha, depth = pr.depth;
+            const float test_T = T * (1.0f - alpha);
+            if (test_T < GSR_T_EPS) { done = true; continue; }
+            const float4 a4 = s_rec[j * 5 + 4];
+            const float w = alpha * T;
+            const float A = 1.0f - T;
+            float dm_dz_unused;
+            const float m_d = gsr_depth_map(depth, dm_dz_unused);
+            dist += (m_d * m_d * A + M2 - 2.0f * m_d * M1) * w;
+            Dacc += depth * w;
+            M1 += m_d * w;
+            M2 += m_d * m_d * w;
+            if (T > 0.5f) { med_depth = depth; med_contrib = contributor; }
+            N0 += a2.w * w; N1 += a3.x * w; N2 += a3.y * w;
+            C0 += a3.w * w; C1 += a4.x * w; C2 += a4.y * w;
+            T = test_T;
+            last_contributor = contributor;
+        }
+        __builtin_amdgcn_wave_barrier();   // all reads of this batch precede the next batch's LDS writes
     }
 
     if (inside) {
@@ -125,13 +144,13 @@ __global__ void __launch_bounds__(RF_BLOCK) render_fwd_kernel(RenderFwdParams p)
     }
 }
 
-int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const uint32_t* point_list,
-                          const float* splat, float* final_T, uint32_t* n_contrib,
-                          float* out_color, float* out_allmap, hipStream_t s) {
+int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* stream,
+                          float* final_T, uint32_t* n_contrib, float* out_color,
+                          float* out_allmap, hipStream_t s) {
     RenderFwdParams p;
     p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE; p.flags = v.flags;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
-    p.ranges = ranges; p.point_list = point_list; p.splat = splat; p.bg = v.bg;
+    p.ranges = ranges; p.stream = reinterpret_cast<const float4*>(stream); p.bg = v.bg;
     p.final_T = final_T; p.n_contrib = n_contrib; p.out_color = out_color; p.out_allmap = out_allmap;
     if (p.gx <= 0 || gy <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_RENDER_FWD, s);
