@@ -38,7 +38,10 @@ struct RenderFwdParams {
     float* final_T; uint32_t* n_contrib; float* out_color; float* out_allmap;
 };
 
-__global__ void __launch_bounds__(RF_BLOCK) render_fwd_kernel(RenderFwdParams p) {
+#ifndef RF_MIN_WAVES
+#define RF_MIN_WAVES 8   // <= 64 VGPRs: measured 0.645 -> 0.59 ms at 1M/1080p
+#endif
+__global__ void __launch_bounds__(RF_BLOCK, RF_MIN_WAVES) render_fwd_kernel(RenderFwdParams p) {
     __shared__ float4 s_rec_all[RF_WAVES][64 * 5];
 
     const int tid = threadIdx.x;
