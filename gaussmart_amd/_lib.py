@@ -24,7 +24,7 @@ GSR_FLAGS_UPSTREAM = 3
 
 KERNEL_NAMES = ("preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
                 "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "loss_fwd", "loss_bwd",
-                "regularizer_fwd", "regularizer_bwd")
+                "regularizer_fwd", "regularizer_bwd", "adam")
 
 
 class GsrView(C.Structure):
@@ -119,6 +119,10 @@ def lib():
         L.gsr_regularizer_backward.restype = C.c_int32
         L.gsr_regularizer_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float,
                                                C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gsr_adam_step.restype = C.c_int32
+        L.gsr_adam_step.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_float),
+                                    C.POINTER(C.c_float), C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.gsr_profile_enable.restype = None
         L.gsr_profile_enable.argtypes = [C.c_int32]
         L.gsr_profile_reset.restype = None

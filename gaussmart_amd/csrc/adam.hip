@@ -1,0 +1,90 @@
+// Dense Adam step over all parameter tensors of the Gaussian model in ONE launch.
+// Same update as torch.optim.Adam (the reference's optimiser: scene/gaussian_model.py:282-295,
+// eps = 1e-15, betas (0.9, 0.999), no weight decay, no amsgrad):
+//     m <- m + (g - m) (1 - b1);  v <- b2 v + (1 - b2) g^2
+//     p <- p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// Dense on purpose: Gaussians outside the current view still decay their moments and move by
+// momentum, exactly as with the reference's optimiser.
+// Pure HBM streaming: 16 B read + 12 B written per parameter (1.62 GB at 1M Gaussians).
+#include "gsr_common.h"
+
+#define AD_BLOCK 256
+#define AD_MAX_TENSORS 8
+
+struct AdamBatch {
+    int count;
+    float beta1, beta2, omb1, omb2, eps;   // 1 - beta is formed in double on the host, like torch does
+    float* p[AD_MAX_TENSORS]; const float* g[AD_MAX_TENSORS]; float* m[AD_MAX_TENSORS]; float* v[AD_MAX_TENSORS];
+    long long n[AD_MAX_TENSORS];
+    float step_size[AD_MAX_TENSORS];     // lr / (1 - beta1^t)
+    float inv_bc2_sqrt[AD_MAX_TENSORS];  // 1 / sqrt(1 - beta2^t)
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float omb1, float b2, float omb2,
+                                         float eps, float step_size, float inv_bc2_sqrt) {
+    m = m + (g - m) * omb1;
+    v = v * b2 + omb2 * g * g;
+    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
+}
+
+__global__ void __launch_bounds__(AD_BLOCK) adam_kernel(AdamBatch b) {
+    const int t = blockIdx.y;
+    if (t >= b.count) return;
+    float* __restrict__ p = b.p[t]; const float* __restrict__ g = b.g[t];
+    float* __restrict__ m = b.m[t]; float* __restrict__ v = b.v[t];
+    const long long n = b.n[t];
+    const float ss = b.step_size[t], ib = b.inv_bc2_sqrt[t];
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
+                       reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const long long n4 = vec ? n / 4 : 0;
+    const long long stride = (long long)gridDim.x * AD_BLOCK;
+    for (long long i = (long long)blockIdx.x * AD_BLOCK + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        adam_one(pp.x, gg.x, mm.x, vv.x, b.omb1, b.beta2, b.omb2, b.eps, ss, ib);
+        adam_one(pp.y, gg.y, mm.y, vv.y, b.omb1, b.beta2, b.omb2, b.eps, ss, ib);
+        adam_one(pp.z, gg.z, mm.z, vv.z, b.omb1, b.beta2, b.omb2, b.eps, ss, ib);
+        adam_one(pp.w, gg.w, mm.w, vv.w, b.omb1, b.beta2, b.omb2, b.eps, ss, ib);
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    for (long long i = n4 * 4 + (long long)blockIdx.x * AD_BLOCK + threadIdx.x; i < n; i += stride) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam_one(pp, g[i], mm, vv, b.omb1, b.beta2, b.omb2, b.eps, ss, ib);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+extern "C" int32_t gsr_adam_step(int32_t count, float* const* params, const float* const* grads,
+                                 float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                                 const float* step_size, const float* inv_bc2_sqrt, double beta1, double beta2,
+                                 double eps, gsr_stream_t stream_) {
+    if (count < 0 || count > AD_MAX_TENSORS) { gsr_set_error("adam: at most %d tensors per call", AD_MAX_TENSORS); return GSR_E_INVALID; }
+    if (count == 0) return GSR_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !step_size || !inv_bc2_sqrt) { gsr_set_error("adam: null argument"); return GSR_E_INVALID; }
+    AdamBatch b;
+    b.count = count; b.beta1 = (float)beta1; b.beta2 = (float)beta2; b.eps = (float)eps;
+    b.omb1 = (float)(1.0 - beta1); b.omb2 = (float)(1.0 - beta2);
+    long long max_n = 0;
+    for (int i = 0; i < count; ++i) {
+        if (numel[i] < 0 || (numel[i] > 0 && (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]))) {
+            gsr_set_error("adam: bad tensor %d", i);
+            return GSR_E_INVALID;
+        }
+        b.p[i] = params[i]; b.g[i] = grads[i]; b.m[i] = exp_avg[i]; b.v[i] = exp_avg_sq[i]; b.n[i] = numel[i];
+        b.step_size[i] = step_size[i]; b.inv_bc2_sqrt[i] = inv_bc2_sqrt[i];
+        if (numel[i] > max_n) max_n = numel[i];
+    }
+    if (max_n == 0) return GSR_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    GsrProfileScope prof(GSR_K_ADAM, s);
+    long long blocks = (max_n / 4 + AD_BLOCK - 1) / AD_BLOCK;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;      // grid-stride beyond 16 blocks per CU
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(AD_BLOCK), 0, s, b);
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}

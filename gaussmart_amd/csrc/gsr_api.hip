@@ -32,7 +32,7 @@ uint32_t g_prof_mask = 0;   // bit k enables timing of kernel id k
 KernelProf g_prof[GSR_K_COUNT];
 const char* const g_kernel_names[GSR_K_COUNT] = {
     "preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
-    "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "loss_fwd", "loss_bwd", "regularizer_fwd", "regularizer_bwd"};
+    "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "loss_fwd", "loss_bwd", "regularizer_fwd", "regularizer_bwd", "adam"};
 constexpr size_t kMaxPending = 1 << 16;
 
 void prof_drain(KernelProf& k) {

@@ -23,7 +23,7 @@ void gsr_set_error(const char* fmt, ...);
 enum GsrKernelId {
     GSR_K_PREPROCESS_FWD = 0, GSR_K_SORT_HIST, GSR_K_SORT_SCATTER, GSR_K_SCAN, GSR_K_EMIT,
     GSR_K_FINALIZE, GSR_K_RENDER_FWD, GSR_K_RENDER_BWD, GSR_K_PREPROCESS_BWD, GSR_K_KNN,
-    GSR_K_LOSS_FWD, GSR_K_LOSS_BWD, GSR_K_REG_FWD, GSR_K_REG_BWD, GSR_K_COUNT
+    GSR_K_LOSS_FWD, GSR_K_LOSS_BWD, GSR_K_REG_FWD, GSR_K_REG_BWD, GSR_K_ADAM, GSR_K_COUNT
 };
 bool gsr_profile_on();
 void gsr_profile_begin(int kernel, hipStream_t s);

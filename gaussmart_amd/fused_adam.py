@@ -1,0 +1,56 @@
+"""torch.optim.Adam whose step() is ONE HIP kernel launch over all parameter groups
+(SURVEY 8(f) N2).  State layout (`exp_avg`, `exp_avg_sq`, `step`) and param_groups are exactly
+torch's, so the reference's optimiser surgery during densification
+(scene/gaussian_model.py:398-470: replace / prune / cat of the moment tensors) works unchanged."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam(torch.optim.Adam):
+    MAX_TENSORS = 8
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib()
+        batches = {}
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise _lib.GsrError("FusedAdam needs contiguous float32 parameters on a HIP device")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                t = float(st["step"])
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                key = (p.device, beta1, beta2, group["eps"])
+                batches.setdefault(key, []).append(
+                    (p, g, st["exp_avg"], st["exp_avg_sq"], group["lr"] / (1.0 - beta1 ** t), 1.0 / math.sqrt(1.0 - beta2 ** t)))
+        for (dev, beta1, beta2, eps), items in batches.items():
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                for i in range(0, len(items), self.MAX_TENSORS):
+                    chunk = items[i:i + self.MAX_TENSORS]
+                    n = len(chunk)
+                    arr = lambda k: (C.c_void_p * n)(*[c[k].data_ptr() for c in chunk])
+                    _lib.check(L.gsr_adam_step(
+                        n, arr(0), arr(1), arr(2), arr(3), (C.c_int64 * n)(*[c[0].numel() for c in chunk]),
+                        (C.c_float * n)(*[c[4] for c in chunk]), (C.c_float * n)(*[c[5] for c in chunk]),
+                        beta1, beta2, eps, C.c_void_p(stream)))
+        return loss

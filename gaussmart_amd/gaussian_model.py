@@ -146,8 +146,11 @@ class GaussianModel:
             {"params": [self._scaling], "lr": training_args.scaling_lr, "name": "scaling"},
             {"params": [self._rotation], "lr": training_args.rotation_lr, "name": "rotation"},
         ]
-        fused = bool(self.use_fused_adam and dev.type == "cuda")
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=fused)
+        if self.use_fused_adam and dev.type == "cuda":
+            from .fused_adam import FusedAdam          # one HIP launch for all six groups
+            self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         self.xyz_scheduler_args = get_expon_lr_func(
             lr_init=training_args.position_lr_init * self.spatial_lr_scale,
             lr_final=training_args.position_lr_final * self.spatial_lr_scale,

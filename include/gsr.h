@@ -177,11 +177,20 @@ int32_t gsr_regularizer_backward(const float* allmap, int32_t H, int32_t W, cons
                                  float depth_ratio, float lambda_normal, float lambda_dist,
                                  const float* grad_scale, float* d_allmap, gsr_stream_t stream);
 
+/* Dense Adam step over up to 8 parameter tensors in one launch; the update of
+ * torch.optim.Adam as the reference configures it (scene/gaussian_model.py:282-295).  All arrays
+ * are HOST arrays of length `count`; the pointers inside are device f32 buffers of numel[i]
+ * elements.  step_size[i] = lr_i / (1 - beta1^t), inv_bc2_sqrt[i] = 1 / sqrt(1 - beta2^t). */
+int32_t gsr_adam_step(int32_t count, float* const* params, const float* const* grads,
+                      float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                      const float* step_size, const float* inv_bc2_sqrt, double beta1, double beta2,
+                      double eps, gsr_stream_t stream);
+
 /* Opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline figures).
  * `mask`: bit k enables kernel k in the order of the names below (-1 = all, 0 = off); timing only
  * the few big kernels keeps the event overhead out of the measured step.
  * Kernel names: "preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
- * "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "loss_fwd", "loss_bwd", "regularizer_fwd", "regularizer_bwd". */
+ * "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "loss_fwd", "loss_bwd", "regularizer_fwd", "regularizer_bwd", "adam". */
 void gsr_profile_enable(int32_t mask);
 void gsr_profile_reset(void);
 int32_t gsr_profile_read(const char* kernel, double* total_ms, int32_t* launches);
