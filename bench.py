@@ -165,8 +165,9 @@ def main():
     torch.cuda.synchronize()
     log("timing")
     big = ("preprocess_fwd", "render_fwd", "render_bwd", "preprocess_bwd")
+    timed = _lib.KERNEL_NAMES if os.environ.get("GSR_BENCH_PROFILE_ALL") else big   # all: adds event overhead
     _lib.profile_reset()
-    _lib.profile_enable(big)
+    _lib.profile_enable(timed)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -215,6 +216,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per_kernel[dom]},
             "kernel_ms": {k: round(v, 4) for k, v in per_kernel.items()},
+            "kernel_ms_per_step": {k: round(ms / args.steps, 4) for k, (ms, n) in prof.items() if n},
             "iteration": {"algorithmic_bytes": iter_b, "hbm_frac": iter_b / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
