@@ -124,9 +124,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
 
     from gaussmart_amd import _lib
     from gaussmart_amd.synthetic import make_scene, perturb, activate, jittered_cameras
@@ -153,7 +154,8 @@ def main():
     model = GaussianModel(3, device=dev)
     model.create_from_params(params)
     model.training_setup(opt)
-    vp = ViewParallel(model) if world > 1 else None
+    force_dp = bool(os.environ.get("GSR_BENCH_FORCE_DP")) and dist.is_initialized()   # rehearsal on one GPU
+    vp = ViewParallel(model, force=force_dp) if (world > 1 or force_dp) else None
 
     base_iter = 10_000
     def step(i):
@@ -223,7 +225,7 @@ def main():
             log(f"GPU part done ({out['value']:.2f} it/s, D={D}); timing the CPU oracle on {host_cores()} cores")
             out["cpu_baseline"] = cpu_baseline(params, cam, args.cpu_tiles, 100_000, dbg, W, H)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
