@@ -119,6 +119,9 @@ def lib():
         L.gsr_regularizer_backward.restype = C.c_int32
         L.gsr_regularizer_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float,
                                                C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gsr_objective_finish.restype = C.c_int32
+        L.gsr_objective_finish.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
+                                           C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.gsr_adam_step.restype = C.c_int32
         L.gsr_adam_step.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_float),

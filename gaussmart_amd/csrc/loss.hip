@@ -185,3 +185,48 @@ extern "C" int32_t gsr_loss_backward(const float* img, const float* gt, const fl
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Objective finish: turns the per-block partials of loss_fwd (and optionally reg_fwd) into the
+// five scalars of the training objective in ONE tiny launch, instead of ~20 zero-dim torch kernels:
+//   out[0] = total = (1-l) * l1 + l * (1 - ssim) + ln * normal + ld * dist
+//   out[1] = l1, out[2] = ssim, out[3] = mean normal error, out[4] = mean distortion
+// Fixed summation order (single workgroup, strided chunks, tree) => reproducible loss value.
+__global__ void __launch_bounds__(256) objective_finish_kernel(const float* __restrict__ pl, int n_pl, float inv_n_img,
+                                                               const float* __restrict__ pr, int n_pr, float inv_n_pix,
+                                                               float lambda_dssim, float lambda_normal, float lambda_dist,
+                                                               float* __restrict__ out) {
+    __shared__ float red[4][256];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int i = threadIdx.x; i < n_pl; i += 256) { s0 += pl[2 * i]; s1 += pl[2 * i + 1]; }
+    for (int i = threadIdx.x; i < n_pr; i += 256) { s2 += pr[2 * i]; s3 += pr[2 * i + 1]; }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2; red[3][threadIdx.x] = s3;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + d];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float ssim = red[0][0] * inv_n_img, l1 = red[1][0] * inv_n_img;
+        const float nrm = red[2][0] * inv_n_pix, dst = red[3][0] * inv_n_pix;
+        out[0] = (1.0f - lambda_dssim) * l1 + lambda_dssim * (1.0f - ssim) + lambda_normal * nrm + lambda_dist * dst;
+        out[1] = l1; out[2] = ssim; out[3] = nrm; out[4] = dst;
+    }
+}
+
+extern "C" int32_t gsr_objective_finish(const float* loss_partials, int32_t C, int32_t H, int32_t W,
+                                        const float* reg_partials, float lambda_dssim, float lambda_normal,
+                                        float lambda_dist, float* out5, gsr_stream_t stream_) {
+    if (!loss_partials || !out5 || C <= 0 || H <= 0 || W <= 0) { gsr_set_error("bad objective_finish arguments"); return GSR_E_INVALID; }
+    const int n = gsr_loss_num_partials(H, W) / 2;
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(objective_finish_kernel, dim3(1), dim3(256), 0, s, loss_partials, n,
+                       1.0f / ((float)C * (float)H * (float)W), reg_partials, reg_partials ? n : 0,
+                       1.0f / ((float)H * (float)W), lambda_dssim, reg_partials ? lambda_normal : 0.f,
+                       reg_partials ? lambda_dist : 0.f, out5);
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}

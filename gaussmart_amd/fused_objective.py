@@ -1,0 +1,88 @@
+"""The complete training objective of one iteration as ONE autograd node on the HIP library:
+
+    total = (1-l)*L1(image, gt) + l*(1 - SSIM(image, gt))                   train.py:113-114
+          + lambda_normal * mean(1 - rend_normal . surf_normal)             train.py:135-139
+          + lambda_dist   * mean(rend_dist)                                 train.py:140
+
+Forward: gsr_loss_forward (+ gsr_regularizer_forward) + gsr_objective_finish = 3 launches;
+backward: gsr_loss_backward (+ gsr_regularizer_backward) = 2 launches.  The same kernels as
+fused_loss.py / fused_regularizer.py, minus the ~25 zero-dimensional torch kernels that combining
+their scalars in Python costs (each ~4.7 us of GPU timeline at this scale).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .fused_regularizer import camera_kinv
+
+
+class _Objective(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, allmap, gt, kinv, lambda_dssim, lambda_normal, lambda_dist, depth_ratio):
+        L = _lib.lib()
+        if image.device.type != "cuda":
+            raise _lib.GsrError("training_objective needs tensors on a HIP device (torch 'cuda'); there is no CPU path")
+        img = image.detach().float().contiguous()
+        tgt = gt.detach().float().contiguous()
+        Cn, H, W = img.shape
+        dev = img.device
+        use_reg = allmap is not None and (lambda_normal > 0.0 or lambda_dist > 0.0)
+        am = allmap.detach().float().contiguous() if use_reg else None
+        with torch.cuda.device(dev):
+            n_part = L.gsr_loss_num_partials(H, W)
+            maps = torch.empty((3, Cn, H, W), dtype=torch.float32, device=dev)
+            partials = torch.empty((2, n_part), dtype=torch.float32, device=dev)
+            out = torch.empty(5, dtype=torch.float32, device=dev)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(L.gsr_loss_forward(C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()), Cn, H, W,
+                                          C.c_void_p(maps.data_ptr()), C.c_void_p(partials[0].data_ptr()), stream))
+            reg_ptr = None
+            if use_reg:
+                _lib.check(L.gsr_regularizer_forward(C.c_void_p(am.data_ptr()), H, W, kinv, float(depth_ratio),
+                                                     C.c_void_p(partials[1].data_ptr()), stream))
+                reg_ptr = C.c_void_p(partials[1].data_ptr())
+            _lib.check(L.gsr_objective_finish(C.c_void_p(partials[0].data_ptr()), Cn, H, W, reg_ptr,
+                                              float(lambda_dssim), float(lambda_normal), float(lambda_dist),
+                                              C.c_void_p(out.data_ptr()), stream))
+        ctx.use_reg = use_reg
+        ctx.cfg = (kinv, float(lambda_dssim), float(lambda_normal), float(lambda_dist), float(depth_ratio))
+        ctx.has_allmap = allmap is not None
+        if use_reg:
+            ctx.save_for_backward(img, tgt, maps, am)
+        else:
+            ctx.save_for_backward(img, tgt, maps)
+        total, parts = out[0], out[1:]
+        ctx.mark_non_differentiable(parts)
+        return total, parts
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        L = _lib.lib()
+        saved = ctx.saved_tensors
+        img, tgt, maps = saved[0], saved[1], saved[2]
+        kinv, ld, ln, ldist, ratio = ctx.cfg
+        Cn, H, W = img.shape
+        dev = img.device
+        dam = None
+        with torch.cuda.device(dev):
+            scale = g_total.detach().float().reshape(1).contiguous()
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            dimg = torch.empty_like(img)
+            _lib.check(L.gsr_loss_backward(C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()), C.c_void_p(maps.data_ptr()),
+                                           Cn, H, W, ld, C.c_void_p(scale.data_ptr()), C.c_void_p(dimg.data_ptr()), stream))
+            if ctx.use_reg:
+                am = saved[3]
+                dam = torch.empty_like(am)
+                _lib.check(L.gsr_regularizer_backward(C.c_void_p(am.data_ptr()), H, W, kinv, ratio, ln, ldist,
+                                                      C.c_void_p(scale.data_ptr()), C.c_void_p(dam.data_ptr()), stream))
+        return dimg, dam, None, None, None, None, None, None
+
+
+def training_objective(image, allmap, gt, viewpoint_camera, lambda_dssim=0.2, lambda_normal=0.0, lambda_dist=0.0,
+                       depth_ratio=0.0):
+    """-> (total, parts) with parts = [l1, ssim, mean normal error, mean distortion] (device tensor)."""
+    use_reg = allmap is not None and (lambda_normal > 0.0 or lambda_dist > 0.0)
+    kinv = camera_kinv(viewpoint_camera) if use_reg else None
+    return _Objective.apply(image, allmap if use_reg else None, gt, kinv, lambda_dssim, lambda_normal, lambda_dist,
+                            depth_ratio)

@@ -13,7 +13,7 @@ import torch
 
 from .gaussian_renderer import render
 from .fused_loss import photometric_loss as fused_photometric_loss
-from .fused_regularizer import surface_regularizer
+from .fused_objective import training_objective
 from .losses import l1_loss, ssim
 from .view_parallel import ViewParallel
 
@@ -30,26 +30,22 @@ def photometric(image, gt_image, lambda_dssim):
 
 
 def training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam=None, pipe=None):
-    """train.py:113-143.  On a HIP device the photometric loss and the surface regularizers each run
-    as one fused kernel per direction; on the host (CPU plumbing tests) the stock torch formulation
-    of the reference is used on the maps render() derived."""
+    """train.py:113-143.  On a HIP device the whole objective (L1 + SSIM + surface regularizers) is
+    one fused autograd node (gaussmart_amd/fused_objective.py); on the host (CPU plumbing tests)
+    the stock torch formulation of the reference is used on the maps render() derived."""
     image = render_pkg["render"]
-    loss, Ll1 = photometric(image, gt_image, opt.lambda_dssim)
     lambda_normal = opt.lambda_normal if iteration > 7000 else 0.0
     lambda_dist = opt.lambda_dist if iteration > 3000 else 0.0
-    if "rend_normal" in render_pkg:
-        normal_error = (1 - (render_pkg["rend_normal"] * render_pkg["surf_normal"]).sum(dim=0))[None]
-        normal_loss = lambda_normal * normal_error.mean()
-        dist_loss = lambda_dist * render_pkg["rend_dist"].mean()
-        total = loss + dist_loss + normal_loss
-    elif lambda_normal > 0.0 or lambda_dist > 0.0:
-        reg, normal_mean, dist_mean = surface_regularizer(render_pkg["allmap"], viewpoint_cam, pipe.depth_ratio,
-                                                          lambda_normal, lambda_dist)
-        normal_loss, dist_loss = lambda_normal * normal_mean, lambda_dist * dist_mean
-        total = loss + reg
-    else:
-        normal_loss = dist_loss = torch.zeros((), device=image.device)
-        total = loss
+    if "rend_normal" not in render_pkg:
+        total, parts = training_objective(image, render_pkg["allmap"], gt_image, viewpoint_cam, opt.lambda_dssim,
+                                          lambda_normal, lambda_dist, pipe.depth_ratio)
+        l1, ssim_v = parts[0], parts[1]
+        return total, {"l1": l1, "ssim": ssim_v, "normal_mean": parts[2], "dist_mean": parts[3], "loss": total.detach()}
+    loss, Ll1 = photometric(image, gt_image, opt.lambda_dssim)
+    normal_error = (1 - (render_pkg["rend_normal"] * render_pkg["surf_normal"]).sum(dim=0))[None]
+    normal_loss = lambda_normal * normal_error.mean()
+    dist_loss = lambda_dist * render_pkg["rend_dist"].mean()
+    total = loss + dist_loss + normal_loss
     return total, {"l1": Ll1.detach(), "loss": loss.detach(), "normal": normal_loss.detach(), "dist": dist_loss.detach()}
 
 

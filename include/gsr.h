@@ -177,6 +177,14 @@ int32_t gsr_regularizer_backward(const float* allmap, int32_t H, int32_t W, cons
                                  float depth_ratio, float lambda_normal, float lambda_dist,
                                  const float* grad_scale, float* d_allmap, gsr_stream_t stream);
 
+/* The whole training objective from the partials of gsr_loss_forward (and, when reg_partials is
+ * non-NULL, gsr_regularizer_forward) in one tiny launch:
+ *   out5 = { (1-l)*l1 + l*(1-ssim) + ln*normal + ld*dist,  l1,  ssim,  mean normal error,  mean dist }
+ * (train.py:113-143).  Fixed summation order => reproducible loss value. */
+int32_t gsr_objective_finish(const float* loss_partials, int32_t C, int32_t H, int32_t W,
+                             const float* reg_partials, float lambda_dssim, float lambda_normal,
+                             float lambda_dist, float* out5, gsr_stream_t stream);
+
 /* Dense Adam step over up to 8 parameter tensors in one launch; the update of
  * torch.optim.Adam as the reference configures it (scene/gaussian_model.py:282-295).  All arrays
  * are HOST arrays of length `count`; the pointers inside are device f32 buffers of numel[i]

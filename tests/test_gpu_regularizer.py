@@ -69,3 +69,36 @@ def test_empty_image_and_odd_sizes(gpu_device):
     assert abs(nm.item() - 1.0) < 1e-6 and dm.item() == 0.0
     assert torch.isfinite(am.grad).all() and float(am.grad[:6].abs().max()) == 0.0
     np.testing.assert_allclose(am.grad[6].cpu().numpy(), 1.0 / (21 * 37), rtol=1e-6)
+
+
+@pytest.mark.parametrize("ln,ld", [(0.05, 0.0), (0.05, 100.0), (0.0, 0.0)])
+def test_fused_objective_vs_oracles(gpu_device, ln, ld):
+    """One autograd node for L1 + SSIM + regularizers: value and both gradients vs the two oracles."""
+    from gaussmart_amd.fused_objective import training_objective
+    from oracle import loss_ref
+    pkg, cam = _allmap_from_render(gpu_device, seed=5)
+    img = pkg["render"].detach()
+    gt = (img + 0.1 * torch.randn_like(img)).clamp(0, 1)
+    am = pkg["allmap"].detach()
+    ih, ah = img.clone().requires_grad_(True), am.clone().requires_grad_(True)
+    total, parts = training_objective(ih, ah, gt, cam, 0.2, ln, ld, 0.0)
+    total.backward()
+    io, ao = img.cpu().double().requires_grad_(True), am.cpu().double().requires_grad_(True)
+    lo, l1o, so = loss_ref.photometric_loss(io, gt.cpu().double(), 0.2)
+    ro, nmo, dmo = R.regularizer_loss(ao, cam.world_view_transform.cpu().double(), cam.full_proj_transform.cpu().double(), 0.0, ln, ld)
+    (lo + ro).backward()
+    np.testing.assert_allclose(total.item(), (lo + ro).item(), rtol=2e-5)
+    np.testing.assert_allclose(parts[0].item(), l1o.item(), rtol=2e-5)
+    np.testing.assert_allclose(parts[1].item(), so.item(), rtol=2e-5)
+    if ln > 0 or ld > 0:
+        np.testing.assert_allclose(parts[2].item(), nmo.item(), rtol=2e-5)
+        np.testing.assert_allclose(parts[3].item(), dmo.item(), rtol=2e-5)
+    gi, gio = ih.grad.cpu().double(), io.grad
+    assert float((gi - gio).abs().max()) <= 2e-4 * float(gio.abs().max())
+    if ln > 0 or ld > 0:
+        ga, gao = ah.grad.cpu().double(), torch.nan_to_num(ao.grad, 0.0, 0.0, 0.0)
+        for c in range(7):
+            sc = float(gao[c].abs().max())
+            assert float((ga[c] - gao[c]).abs().max()) <= 2e-3 * sc + 1e-12
+    else:
+        assert ah.grad is None or float(ah.grad.abs().max()) == 0.0
