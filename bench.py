@@ -145,6 +145,8 @@ def main():
     cam = jittered_cameras(world, W, H, seed=0, device=dev)[rank]   # one view per rank
     bg = torch.zeros(3, device=dev)
     pipe, opt = PipelineParams(), OptimizationParams()
+    if os.environ.get("GSR_BENCH_PLAIN_ACTIVATIONS"):      # A/B aid: torch activations + reference-signature operator
+        pipe.fused_activations = False
 
     target = GaussianModel(3, device=dev)
     target.create_from_params(perturb(params))

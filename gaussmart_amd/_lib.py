@@ -15,12 +15,14 @@ import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgsr_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 GSR_BUF_GEOM, GSR_BUF_BINNING, GSR_BUF_IMAGE, GSR_BUF_SCRATCH, GSR_BUF_SCRATCH2 = range(5)
 GSR_FLAG_CLAMP_PASSTHROUGH = 1
 GSR_FLAG_FILTER_DEPTH_GRAD = 2
 GSR_FLAGS_UPSTREAM = 3
+GSR_FLAG_DEBUG_NO_CULL = 4
+GSR_FLAG_RAW_PARAMS = 8
 
 KERNEL_NAMES = ("preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
                 "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "loss_fwd", "loss_bwd",
@@ -40,7 +42,7 @@ class GsrGaussians(C.Structure):
     _fields_ = [("count", C.c_int32),
                 ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
                 ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
-                ("transmat_precomp", C.c_void_p)]
+                ("transmat_precomp", C.c_void_p), ("shs_rest", C.c_void_p)]
 
 
 class GsrForwardOut(C.Structure):
@@ -52,7 +54,7 @@ class GsrForwardOut(C.Structure):
 class GsrGrads(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dopacity", C.c_void_p),
                 ("dL_dshs", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_dscales", C.c_void_p),
-                ("dL_drotations", C.c_void_p), ("dL_dtransmat", C.c_void_p)]
+                ("dL_drotations", C.c_void_p), ("dL_dtransmat", C.c_void_p), ("dL_dshs_rest", C.c_void_p)]
 
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)

@@ -113,6 +113,8 @@ static int validate(const GsrView* v, const GsrGaussians* g) {
             return GSR_E_INVALID;
         }
     }
+    if (g->shs_rest && (!g->shs || v->sh_coeffs < 2)) { gsr_set_error("shs_rest given without shs (dc) or with fewer than 2 coefficients"); return GSR_E_INVALID; }
+    if ((v->flags & (uint32_t)GSR_FLAG_RAW_PARAMS) && g->transmat_precomp) { gsr_set_error("raw parameters and transmat_precomp are mutually exclusive"); return GSR_E_INVALID; }
     if (g->count > 0 && (!g->means3D || !g->opacities)) { gsr_set_error("means3D / opacities missing"); return GSR_E_INVALID; }
     if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos) { gsr_set_error("view pointers missing"); return GSR_E_INVALID; }
     return GSR_OK;
@@ -234,7 +236,7 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     if (rc != GSR_OK) return rc;
     if (!grads || !alloc || !geom || !binning || !image || !dL_dcolor || !dL_dallmap || num_rendered < 0 ||
         (g->count > 0 && (!radii || !grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacity)) ||
-        (g->shs && !grads->dL_dshs) || (g->colors_precomp && !grads->dL_dcolors) ||
+        (g->shs && !grads->dL_dshs) || (g->shs_rest && !grads->dL_dshs_rest) || (g->colors_precomp && !grads->dL_dcolors) ||
         (g->scales && (!grads->dL_dscales || !grads->dL_drotations)) ||
         (g->transmat_precomp && !grads->dL_dtransmat)) {
         gsr_set_error("backward inputs / gradient outputs missing");
@@ -265,6 +267,7 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     }
     GsrGrads o = *grads;
     if (!g->shs) o.dL_dshs = nullptr;
+    if (!g->shs_rest) o.dL_dshs_rest = nullptr;
     if (!g->colors_precomp) o.dL_dcolors = nullptr;
     if (!g->scales) { o.dL_dscales = nullptr; o.dL_drotations = nullptr; }
     if (!g->transmat_precomp) o.dL_dtransmat = nullptr;

@@ -8,16 +8,17 @@
 // HBM-bound: reads 80 B x instances + 232 B, writes 232 B (192 of them dSH) per Gaussian; the SH
 // block is staged through LDS both ways so global traffic is coalesced 16-byte accesses.
 #include "gsr_common.h"
+#include "sh_stage.h"
 
 #define PB_BLOCK 256
-#define SH_ROW_FLOATS 52
 
 struct PreBwdParams {
     int N, W, H;
     int deg, M;
     float mod;
     const float* view; const float* proj; const float* campos;
-    const float* means; const float* shs; const float* scales; const float* rots;
+    bool raw;
+    const float* means; const float* shs; const float* shs_rest; const float* opac; const float* scales; const float* rots;
     const float* tprecomp;
     const int32_t* radii; const float* splat; const uint32_t* clamped;
     const uint32_t* tiles; const uint32_t* inst_begin; const float* grad_rows; const uint32_t* row_flags;
@@ -37,18 +38,8 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
 
     float* wl = lds + wave * 64 * SH_ROW_FLOATS;
     float* my_sh = wl + lane * SH_ROW_FLOATS;
-    if (STAGE_SH && n_here > 0) {
-        const float4* src = reinterpret_cast<const float4*>(p.shs + (size_t)wave_first * row_f);
-        const int vec_per_row = row_f >> 2;
-        const int total_vec = n_here * vec_per_row;
-        for (int v = lane; v < total_vec; v += 64) {
-            const float4 d = src[v];
-            const int row = v / vec_per_row, col = (v - row * vec_per_row) << 2;
-            *reinterpret_cast<float4*>(wl + row * SH_ROW_FLOATS + col) = d;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
+    if (STAGE_SH)
+        sh_stage<true>(wl, const_cast<float*>(p.shs), const_cast<float*>(p.shs_rest), p.M, wave_first, n_here, lane);
 
     const bool valid = idx < p.N;
     const bool visible = valid && p.radii[idx] > 0;
@@ -139,7 +130,9 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
             const float r00 = 1.f - 2.f * (qy * qy + qz * qz), r10 = 2.f * (qx * qy + qw * qz), r20 = 2.f * (qx * qz - qw * qy);
             const float r01 = 2.f * (qx * qy - qw * qz), r11 = 1.f - 2.f * (qx * qx + qz * qz), r21 = 2.f * (qy * qz + qw * qx);
             const float r02 = 2.f * (qx * qz + qw * qy), r12 = 2.f * (qy * qz - qw * qx), r22 = 1.f - 2.f * (qx * qx + qy * qy);
-            const float sx = p.scales[2 * idx + 0] * p.mod, sy = p.scales[2 * idx + 1] * p.mod;
+            float sx = p.scales[2 * idx + 0], sy = p.scales[2 * idx + 1];
+            if (p.raw) { sx = expf(sx); sy = expf(sy); }
+            sx *= p.mod; sy *= p.mod;
 
             // normal = sign * (R[:,2] @ V3); the sign is recomputed exactly like the forward
             const float* V = p.view;
@@ -167,6 +160,13 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
             const float gy = 2.f * (-2.f * qy * d00 + qx * d01 + qw * d02 + qx * d10 + qz * d12 - qw * d20 + qz * d21 - 2.f * qy * d22);
             const float gz = 2.f * (-2.f * qz * d00 - qw * d01 + qx * d02 + qw * d10 - 2.f * qz * d11 + qy * d12 + qx * d20 + qy * d21);
             dq[0] = gr * s; dq[1] = gx * s; dq[2] = gy * s; dq[3] = gz * s;
+            if (p.raw) {
+                // through the activations: exp for the scales, normalize for the quaternion
+                dscale0 *= sx / p.mod; dscale1 *= sy / p.mod;      // d exp(x)/dx = exp(x)
+                const float qd = qw * gr + qx * gx + qy * gy + qz * gz;
+                dq[0] = (gr - qw * qd) * s; dq[1] = (gx - qx * qd) * s;
+                dq[2] = (gy - qy * qd) * s; dq[3] = (gz - qz * qd) * s;
+            }
         }
     }
 
@@ -254,15 +254,7 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (n_here > 0) {
-                float4* dst = reinterpret_cast<float4*>(p.out.dL_dshs + (size_t)wave_first * row_f);
-                const int vec_per_row = row_f >> 2;
-                const int total_vec = n_here * vec_per_row;
-                for (int v = lane; v < total_vec; v += 64) {
-                    const int row = v / vec_per_row, col = (v - row * vec_per_row) << 2;
-                    dst[v] = *reinterpret_cast<const float4*>(wl + row * SH_ROW_FLOATS + col);
-                }
-            }
+            sh_stage<false>(wl, p.out.dL_dshs, p.out.dL_dshs_rest, p.M, wave_first, n_here, lane);
         } else if (valid) {
             float* o = p.out.dL_dshs + (size_t)idx * row_f;
             for (int k = 0; k < p.M; ++k) {
@@ -279,6 +271,10 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
     p.out.dL_dmeans2D[3 * idx + 0] = d2d0;
     p.out.dL_dmeans2D[3 * idx + 1] = d2d1;
     p.out.dL_dmeans2D[3 * idx + 2] = 0.f;
+    if (p.raw && visible) {
+        const float o = 1.0f / (1.0f + expf(-p.opac[idx]));
+        dopa *= o * (1.0f - o);                                 // d sigmoid
+    }
     p.out.dL_dopacity[idx] = dopa;
     if (p.out.dL_dcolors) {
         p.out.dL_dcolors[3 * idx + 0] = drgb[0]; p.out.dL_dcolors[3 * idx + 1] = drgb[1]; p.out.dL_dcolors[3 * idx + 2] = drgb[2];
@@ -303,14 +299,14 @@ int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int
     PreBwdParams p;
     p.N = g.count; p.W = v.width; p.H = v.height; p.deg = v.sh_degree; p.M = v.sh_coeffs;
     p.mod = v.scale_modifier; p.view = v.viewmatrix; p.proj = v.projmatrix; p.campos = v.campos;
-    p.means = g.means3D; p.shs = g.shs; p.scales = g.scales; p.rots = g.rotations;
+    p.raw = (v.flags & (uint32_t)GSR_FLAG_RAW_PARAMS) != 0;
+    p.means = g.means3D; p.shs = g.shs; p.shs_rest = g.shs_rest; p.opac = g.opacities; p.scales = g.scales; p.rots = g.rotations;
     p.tprecomp = g.transmat_precomp; p.radii = radii; p.splat = splat; p.clamped = clamped;
     p.tiles = tiles_touched; p.inst_begin = inst_begin; p.grad_rows = grad_rows; p.row_flags = row_flags; p.out = out;
     const int blocks = (g.count + PB_BLOCK - 1) / PB_BLOCK;
     GsrProfileScope prof(GSR_K_PREPROCESS_BWD, s);
-    const bool stage = g.shs != nullptr && v.sh_coeffs * 3 <= 48 && (v.sh_coeffs * 3) % 4 == 0 &&
-                       (reinterpret_cast<uintptr_t>(g.shs) & 15) == 0 &&
-                       (reinterpret_cast<uintptr_t>(out.dL_dshs) & 15) == 0;
+    const bool stage = sh_can_stage(g.shs, g.shs_rest, v.sh_coeffs) && sh_can_stage(out.dL_dshs, out.dL_dshs_rest, v.sh_coeffs);
+    if (g.shs_rest && (!stage || !out.dL_dshs_rest)) { gsr_set_error("split SH storage needs 16-byte aligned pointers, <= 16 coefficients and dL_dshs_rest"); return GSR_E_UNSUPPORTED; }
     if (stage) {
         const size_t lds_bytes = (size_t)(PB_BLOCK / 64) * 64 * SH_ROW_FLOATS * sizeof(float);
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(PB_BLOCK), lds_bytes, s, p);

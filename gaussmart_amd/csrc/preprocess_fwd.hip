@@ -10,16 +10,17 @@
 // 16-byte loads into a wave-private LDS tile with 208-byte rows (conflict-free ds_read_b128 by
 // row) instead of 48 strided dword loads per lane.
 #include "gsr_common.h"
+#include "sh_stage.h"
 
 #define PRE_BLOCK 256
-#define SH_ROW_FLOATS 52   // 48 + 4 pad: 16-byte aligned rows, bank-conflict-free b128 reads
 
 struct PreParams {
     int N, W, H, gx, gy;
     int deg, M;
     float mod;
     const float* view; const float* proj; const float* campos;
-    const float* means; const float* shs; const float* colors; const float* opac;
+    bool raw;
+    const float* means; const float* shs; const float* shs_rest; const float* colors; const float* opac;
     const float* scales; const float* rots; const float* tprecomp;
     float* splat; uint32_t* clamped; uint32_t* tiles; uint32_t* dkey; int32_t* radii;
 };
@@ -69,24 +70,12 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
 
     float* my_sh = nullptr;
     if (STAGE_SH) {
-        // cooperative, fully coalesced fetch of this wave's 64 x (M*3) floats; M*3 % 4 == 0 here
+        // cooperative, fully coalesced fetch of this wave's 64 SH blocks (wave-private LDS region:
+        // LDS ops of one wave complete in order, no workgroup barrier needed)
         float* wl = lds + wave * 64 * SH_ROW_FLOATS;
-        const int row_f = p.M * 3;                 // 48 for degree-3 storage
-        const int n_here = min(64, p.N - wave_first);
-        if (n_here > 0) {
-            const float4* src = reinterpret_cast<const float4*>(p.shs + (size_t)wave_first * row_f);
-            const int vec_per_row = row_f >> 2;
-            const int total_vec = n_here * vec_per_row;
-            for (int v = lane; v < total_vec; v += 64) {
-                float4 d = src[v];
-                int row = v / vec_per_row, col = (v - row * vec_per_row) << 2;
-                *reinterpret_cast<float4*>(wl + row * SH_ROW_FLOATS + col) = d;
-            }
-        }
+        sh_stage<true>(wl, const_cast<float*>(p.shs), const_cast<float*>(p.shs_rest), p.M, wave_first,
+                       min(64, p.N - wave_first), lane);
         my_sh = wl + lane * SH_ROW_FLOATS;
-        // wave-private region: LDS ops of one wave complete in order, no workgroup barrier needed
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
     if (idx >= p.N) return;
 
@@ -113,7 +102,9 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
         const float r00 = 1.f - 2.f * (qy * qy + qz * qz), r10 = 2.f * (qx * qy + qw * qz), r20 = 2.f * (qx * qz - qw * qy);
         const float r01 = 2.f * (qx * qy - qw * qz), r11 = 1.f - 2.f * (qx * qx + qz * qz), r21 = 2.f * (qy * qz + qw * qx);
         const float r02 = 2.f * (qx * qz + qw * qy), r12 = 2.f * (qy * qz - qw * qx), r22 = 1.f - 2.f * (qx * qx + qy * qy);
-        const float sx = p.scales[2 * idx + 0] * p.mod, sy = p.scales[2 * idx + 1] * p.mod;
+        float sx = p.scales[2 * idx + 0], sy = p.scales[2 * idx + 1];
+        if (p.raw) { sx = expf(sx); sy = expf(sy); }          // scaling_activation = exp
+        sx *= p.mod; sy *= p.mod;
         const float rows[3][4] = {{r00 * sx, r10 * sx, r20 * sx, 0.f},
                                   {r01 * sy, r11 * sy, r21 * sy, 0.f},
                                   {px, py, pz, 1.f}};
@@ -176,6 +167,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
         rgb = make_float3(p.colors[3 * idx], p.colors[3 * idx + 1], p.colors[3 * idx + 2]);
     }
 
+    const float opacity = p.raw ? 1.0f / (1.0f + expf(-p.opac[idx])) : p.opac[idx];   // opacity_activation = sigmoid
     // conservative pixel box of {pixels where alpha can reach 1/255}:
     //   alpha = opa * exp(-rho/2) >= 1/255  <=>  rho = min(rho3d, rho2d) <= rho_max = 2 ln(255 opa)
     //   rho2d <= rho_max : disc of radius sqrt(rho_max / 2) around the AABB centre
@@ -184,7 +176,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
     //                      of the camera plane, d < 0; otherwise no culling)
     uint32_t rect_x = 0x7FFF8000u, rect_y = 0x7FFF8000u;   // [-32768, 32767]: never culled
     {
-        const float opa = p.opac[idx];
+        const float opa = opacity;
         const float c2 = (fmaxf(2.0f * logf(255.0f * opa), 0.0f) + 0.05f) * 1.02f;
         if (255.0f * opa < 0.999f) {
             rect_x = 0x80007FFFu; rect_y = 0x80007FFFu;     // x0 = 32767 > x1 = -32768: cannot reach 1/255 anywhere
@@ -218,7 +210,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
     rec[0] = make_float4(Tu[0], Tu[1], Tu[2], Tv[0]);
     rec[1] = make_float4(Tv[1], Tv[2], Tw[0], Tw[1]);
     rec[2] = make_float4(Tw[2], cx, cy, nrm[0]);
-    rec[3] = make_float4(nrm[1], nrm[2], p.opac[idx], rgb.x);
+    rec[3] = make_float4(nrm[1], nrm[2], opacity, rgb.x);
     rec[4] = make_float4(rgb.y, rgb.z, __uint_as_float(rect_x), __uint_as_float(rect_y));
     p.clamped[idx] = clamp_bits;
     p.radii[idx] = (int)radius;
@@ -235,14 +227,14 @@ int gsr_launch_preprocess_fwd(const GsrView& v, const GsrGaussians& g, float* sp
     p.gx = (v.width + GSR_TILE - 1) / GSR_TILE; p.gy = (v.height + GSR_TILE - 1) / GSR_TILE;
     p.deg = v.sh_degree; p.M = v.sh_coeffs; p.mod = v.scale_modifier;
     p.view = v.viewmatrix; p.proj = v.projmatrix; p.campos = v.campos;
-    p.means = g.means3D; p.shs = g.shs; p.colors = g.colors_precomp; p.opac = g.opacities;
+    p.raw = (v.flags & (uint32_t)GSR_FLAG_RAW_PARAMS) != 0;
+    p.means = g.means3D; p.shs = g.shs; p.shs_rest = g.shs_rest; p.colors = g.colors_precomp; p.opac = g.opacities;
     p.scales = g.scales; p.rots = g.rotations; p.tprecomp = g.transmat_precomp;
     p.splat = splat; p.clamped = clamped; p.tiles = tiles_touched; p.dkey = depth_key; p.radii = radii;
     const int blocks = (g.count + PRE_BLOCK - 1) / PRE_BLOCK;
     GsrProfileScope prof(GSR_K_PREPROCESS_FWD, s);
-    // LDS staging needs whole 16-byte vectors per row and rows that fit the padded tile
-    const bool stage = g.shs != nullptr && v.sh_coeffs * 3 <= 48 && (v.sh_coeffs * 3) % 4 == 0 &&
-                       (reinterpret_cast<uintptr_t>(g.shs) & 15) == 0;
+    const bool stage = sh_can_stage(g.shs, g.shs_rest, v.sh_coeffs);
+    if (g.shs_rest && !stage) { gsr_set_error("split SH storage needs 16-byte aligned pointers and <= 16 coefficients"); return GSR_E_UNSUPPORTED; }
     if (stage) {
         const size_t lds_bytes = (size_t)(PRE_BLOCK / 64) * 64 * SH_ROW_FLOATS * sizeof(float);
         hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(blocks), dim3(PRE_BLOCK), lds_bytes, s, p);

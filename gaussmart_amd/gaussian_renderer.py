@@ -14,8 +14,10 @@ import math
 
 import torch
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_raw
 from .sh import eval_sh
+
+_HipRasterizer = GaussianRasterizer   # tests may monkeypatch `GaussianRasterizer`; the raw path is HIP-only
 
 
 def _camera_rays(view, device, dtype):
@@ -59,6 +61,20 @@ def depth_to_normal(view, depth):
     return output
 
 
+def _use_raw_path(pc, pipe, override_color, xyz):
+    """Opt-in (pipe.fused_activations) fast path: only when the model exposes the raw parameter
+    tensors with the reference's activations (exp / sigmoid / normalize) and nothing is overridden."""
+    if not getattr(pipe, "fused_activations", False) or override_color is not None or not xyz.is_cuda:
+        return False
+    if getattr(pipe, "compute_cov3D_python", False) or GaussianRasterizer is not _HipRasterizer:
+        return False
+    need = ("_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    if not all(hasattr(pc, a) for a in need):
+        return False
+    return (getattr(pc, "scaling_activation", None) is torch.exp and getattr(pc, "opacity_activation", None) is torch.sigmoid
+            and getattr(pc, "rotation_activation", None) is torch.nn.functional.normalize)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, *,
            surface_maps=True):
     xyz = pc.get_xyz
@@ -81,7 +97,9 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         prefiltered=False, debug=False)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
-    means3D, means2D, opacity = xyz, screenspace_points, pc.get_opacity
+    raw = _use_raw_path(pc, pipe, override_color, xyz)
+    means3D, means2D = xyz, screenspace_points
+    opacity = None if raw else pc.get_opacity
     scales = rotations = cov3D_precomp = None
     if getattr(pipe, "compute_cov3D_python", False):
         # T matrix assembled in Python, rows (Tu, Tv, Tw) flattened: gaussian_renderer/__init__.py:62-75
@@ -92,7 +110,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
                                 [0, 0, far - near, near], [0, 0, 0, 1]], dtype=torch.float32, device=device).T
         world2pix = viewpoint_camera.full_proj_transform @ ndc2pix
         cov3D_precomp = (splat2world[:, [0, 1, 3]] @ world2pix[:, [0, 1, 3]]).permute(0, 2, 1).reshape(-1, 9)
-    else:
+    elif not raw:
         scales, rotations = pc.get_scaling, pc.get_rotation
 
     shs = colors_precomp = None
@@ -101,14 +119,19 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
             d = xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
             colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, d / d.norm(dim=1, keepdim=True)) + 0.5, 0.0)
-        else:
+        elif not raw:
             shs = pc.get_features
     else:
         colors_precomp = override_color
 
-    rendered_image, radii, allmap = rasterizer(
-        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
-        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    if raw:
+        # same kernels, activations + dc|rest concatenation fused inside (rasterizer.py: _RasterizeGaussiansRaw)
+        rendered_image, radii, allmap = rasterize_gaussians_raw(
+            xyz, means2D, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation, raster_settings)
+    else:
+        rendered_image, radii, allmap = rasterizer(
+            means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
 
     rets = {"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii,
             "allmap": allmap}

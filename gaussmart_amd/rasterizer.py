@@ -62,23 +62,54 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+_WORKSPACE = {}   # (device, stream, which) -> grow-only scratch buffer
+
+
+def _round_up(n, q):
+    return (int(n) + q - 1) // q * q
+
+
 class _Allocator:
-    """Hands torch-owned device memory to the library (include/gsr.h: gsr_alloc_fn)."""
+    """Hands torch-owned device memory to the library (include/gsr.h: gsr_alloc_fn).
+
+    Scratch buffers (only live inside one library call) come from a grow-only per-(device, stream)
+    workspace with 25 % headroom: their size follows the instance count D, which drifts every
+    iteration, and re-requesting ever slightly larger 1 GB blocks from the caching allocator means
+    hipMalloc calls (each a device synchronisation) in the middle of the training loop.  Buffers the
+    backward needs later (geom / binning / image) are ordinary tensors, rounded up to 32 MiB so the
+    caching allocator sees few distinct sizes."""
 
     def __init__(self, device):
         self.device = device
         self.buffers = {}
         self.error = None
+        self.stream = torch.cuda.current_stream(device).cuda_stream
         self.cb = _lib.ALLOC_FN(self._alloc)
 
     def _alloc(self, _ctx, which, nbytes):
         try:
-            t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
-            self.buffers[int(which)] = t
+            which, nbytes = int(which), max(int(nbytes), 1)
+            if which in (_lib.GSR_BUF_SCRATCH, _lib.GSR_BUF_SCRATCH2):
+                key = (self.device, self.stream, which)
+                t = _WORKSPACE.get(key)
+                if t is None or t.numel() < nbytes:
+                    _WORKSPACE.pop(key, None)
+                    t = None
+                    t = torch.empty(_round_up(nbytes + nbytes // 4, 1 << 25), dtype=torch.uint8, device=self.device)
+                    _WORKSPACE[key] = t
+            else:
+                t = torch.empty(_round_up(nbytes, 1 << 25) if nbytes > (1 << 25) else nbytes, dtype=torch.uint8,
+                                device=self.device)
+            self.buffers[which] = t
             return t.data_ptr()
         except Exception as e:  # surfaces as GSR_E_ALLOC
             self.error = e
             return 0
+
+
+def release_workspace():
+    """Drop the cached scratch buffers (e.g. before handing the GPU to something else)."""
+    _WORKSPACE.clear()
 
 
 def _make_view(rs: GaussianRasterizationSettings, sh_coeffs: int, flags: int, device):
@@ -120,7 +151,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(device):
             view, keep = _make_view(rs, sh_coeffs, flags, device)
             g = _lib.GsrGaussians(N, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities),
-                                  _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp))
+                                  _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp), None)
             color = torch.empty((3, H, W), dtype=torch.float32, device=device)
             allmap = torch.empty((7, H, W), dtype=torch.float32, device=device)
             radii = torch.empty((N,), dtype=torch.int32, device=device)
@@ -173,7 +204,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(device):
             view, keep = _make_view(rs, sh.shape[1] if sh is not None else 0, ctx.flags, device)
             g = _lib.GsrGaussians(N, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities),
-                                  _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp))
+                                  _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp), None)
             d_means3D = torch.empty_like(means3D)
             d_means2D = torch.empty((N, 3), dtype=torch.float32, device=device)
             d_opac = torch.empty_like(opacities)
@@ -183,7 +214,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_rot = torch.empty_like(rotations) if rotations is not None else None
             d_cov = torch.empty_like(cov3Ds_precomp) if cov3Ds_precomp is not None else None
             grads = _lib.GsrGrads(_ptr(d_means3D), _ptr(d_means2D), _ptr(d_opac), _ptr(d_sh), _ptr(d_col),
-                                  _ptr(d_scales), _ptr(d_rot), _ptr(d_cov))
+                                  _ptr(d_scales), _ptr(d_rot), _ptr(d_cov), None)
             alloc = _Allocator(device)
             stream = torch.cuda.current_stream(device).cuda_stream
             rc = L.gsr_backward(C.byref(view), C.byref(g), ctx.num_rendered, _ptr(radii), _ptr(geom),
@@ -194,6 +225,90 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.check(rc)
         del keep
         return (d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, None)
+
+
+class _RasterizeGaussiansRaw(torch.autograd.Function):
+    """Same kernels, fed with the model's RAW parameters (GSR_FLAG_RAW_PARAMS + split SH storage):
+    sigmoid / exp / normalize of scene/gaussian_model.py:37-43 and the dc|rest concatenation of
+    :116-119 happen inside preprocess_fwd, their derivatives inside preprocess_bwd.  Saves ~20
+    element-wise launches and two 192 MB copies per iteration; results equal the activated path."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings, flags):
+        L = _lib.lib()
+        device = xyz.device
+        if device.type != "cuda":
+            raise _lib.GsrError("GaussianRasterizer needs tensors on a HIP device (torch 'cuda'); there is no CPU path")
+        rs = raster_settings
+        N = xyz.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        xyz, f_dc, f_rest = _f32c(xyz, "xyz", device), _f32c(f_dc, "features_dc", device), _f32c(f_rest, "features_rest", device)
+        opacity_raw, scaling_raw = _f32c(opacity_raw, "opacity", device), _f32c(scaling_raw, "scaling", device)
+        rotation_raw = _f32c(rotation_raw, "rotation", device)
+        if f_dc.dim() != 3 or f_dc.shape[1] != 1 or f_rest.dim() != 3 or f_rest.shape[0] != N:
+            raise ValueError("features_dc must be [N,1,3] and features_rest [N,K-1,3]")
+        M = 1 + f_rest.shape[1]
+        flags = int(flags) | _lib.GSR_FLAG_RAW_PARAMS
+        rest = f_rest if f_rest.shape[1] > 0 else None
+        with torch.cuda.device(device):
+            view, keep = _make_view(rs, M, flags, device)
+            g = _lib.GsrGaussians(N, _ptr(xyz), _ptr(f_dc), None, _ptr(opacity_raw), _ptr(scaling_raw),
+                                  _ptr(rotation_raw), None, _ptr(rest) if rest is not None else None)
+            color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+            allmap = torch.empty((7, H, W), dtype=torch.float32, device=device)
+            radii = torch.empty((N,), dtype=torch.int32, device=device)
+            out = _lib.GsrForwardOut(color.data_ptr(), allmap.data_ptr(), radii.data_ptr(), 0, None, None, None)
+            alloc = _Allocator(device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            rc = L.gsr_forward(C.byref(view), C.byref(g), C.byref(out), alloc.cb, None, C.c_void_p(stream))
+            if rc != 0 and alloc.error is not None:
+                raise alloc.error
+            _lib.check(rc)
+        ctx.raster_settings, ctx.flags, ctx.num_rendered, ctx.M = rs, flags, int(out.num_rendered), M
+        ctx.save_for_backward(xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, radii,
+                              alloc.buffers[_lib.GSR_BUF_GEOM], alloc.buffers[_lib.GSR_BUF_BINNING],
+                              alloc.buffers[_lib.GSR_BUF_IMAGE])
+        del keep
+        ctx.mark_non_differentiable(radii)
+        return color, radii, allmap
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii, grad_allmap):
+        L = _lib.lib()
+        xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, radii, geom, binning, image = ctx.saved_tensors
+        rs = ctx.raster_settings
+        device = xyz.device
+        N = xyz.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        grad_color = _f32c(grad_color, "grad_color", device) if grad_color is not None else torch.zeros((3, H, W), device=device)
+        grad_allmap = _f32c(grad_allmap, "grad_allmap", device) if grad_allmap is not None else torch.zeros((7, H, W), device=device)
+        rest = f_rest if f_rest.shape[1] > 0 else None
+        with torch.cuda.device(device):
+            view, keep = _make_view(rs, ctx.M, ctx.flags, device)
+            g = _lib.GsrGaussians(N, _ptr(xyz), _ptr(f_dc), None, _ptr(opacity_raw), _ptr(scaling_raw),
+                                  _ptr(rotation_raw), None, _ptr(rest) if rest is not None else None)
+            d_xyz, d_2d = torch.empty_like(xyz), torch.empty((N, 3), dtype=torch.float32, device=device)
+            d_dc, d_rest = torch.empty_like(f_dc), torch.empty_like(f_rest)
+            d_op, d_sc, d_rot = torch.empty_like(opacity_raw), torch.empty_like(scaling_raw), torch.empty_like(rotation_raw)
+            grads = _lib.GsrGrads(_ptr(d_xyz), _ptr(d_2d), _ptr(d_op), _ptr(d_dc), None, _ptr(d_sc), _ptr(d_rot), None,
+                                  _ptr(d_rest) if rest is not None else None)
+            alloc = _Allocator(device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            rc = L.gsr_backward(C.byref(view), C.byref(g), ctx.num_rendered, _ptr(radii), _ptr(geom), _ptr(binning),
+                                _ptr(image), _ptr(grad_color), _ptr(grad_allmap), C.byref(grads), alloc.cb, None,
+                                C.c_void_p(stream))
+            if rc != 0 and alloc.error is not None:
+                raise alloc.error
+            _lib.check(rc)
+        del keep
+        return d_xyz, d_2d, d_dc, d_rest, d_op, d_sc, d_rot, None, None
+
+
+def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
+                            raster_settings, flags=None):
+    """(color, radii, allmap) from the model's raw parameter tensors; activations fused in-kernel."""
+    return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
+                                        rotation_raw, raster_settings, DEFAULT_FLAGS if flags is None else flags)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -242,7 +357,7 @@ def rasterize_debug(means3D, opacities, shs=None, colors_precomp=None, scales=No
                                              (rotations, "rotations"), (cov3D_precomp, "cov3D"))]
     with torch.cuda.device(device), torch.no_grad():
         view, keep = _make_view(rs, args[1].shape[1] if args[1] is not None else 0, flags, device)
-        g = _lib.GsrGaussians(N, *[_ptr(a) for a in args])
+        g = _lib.GsrGaussians(N, *[_ptr(a) for a in args], None)
         color = torch.empty((3, H, W), dtype=torch.float32, device=device)
         allmap = torch.empty((7, H, W), dtype=torch.float32, device=device)
         radii = torch.empty((N,), dtype=torch.int32, device=device)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2
 
 typedef void* gsr_stream_t; /* hipStream_t */
 
@@ -49,7 +49,11 @@ enum {
     GSR_FLAG_CLAMP_PASSTHROUGH = 1, /* gradient flows through alpha = min(0.99, o*G) when clamped */
     GSR_FLAG_FILTER_DEPTH_GRAD = 2, /* low-pass branch: dL/dz also added to dL/dTw.x,.y times s   */
     GSR_FLAGS_UPSTREAM = 3,
-    GSR_FLAG_DEBUG_NO_CULL = 4      /* test aid: ignore the per-wave cull rect (results are bit-identical) */
+    GSR_FLAG_DEBUG_NO_CULL = 4,     /* test aid: ignore the per-wave cull rect (results are bit-identical) */
+    GSR_FLAG_RAW_PARAMS = 8         /* opacities are logits, scales are log-scales, rotations un-normalised:
+                                       the activations of scene/gaussian_model.py:37-43 (sigmoid, exp,
+                                       normalize) run inside the kernels and the gradients returned are
+                                       w.r.t. the raw parameters */
 };
 
 /* GaussianRasterizationSettings (gaussian_renderer/__init__.py:37-51) */
@@ -78,6 +82,9 @@ typedef struct GsrGaussians {
     const float* scales;           /* device [N,2] (post-exp) or NULL                */
     const float* rotations;        /* device [N,4] (w,x,y,z) or NULL                 */
     const float* transmat_precomp; /* device [N,9] rows Tu,Tv,Tw, or NULL            */
+    const float* shs_rest;         /* device [N,M-1,3] or NULL.  When non-NULL, `shs` holds only
+                                      the DC coefficient [N,1,3] (split storage = the model's two
+                                      feature parameters, no concatenation needed)               */
 } GsrGaussians;
 
 /* Buffers the forward hands to the backward.  The caller allocates them through the callback
@@ -111,6 +118,7 @@ typedef struct GsrGrads {
     float* dL_dscales;    /* device [N,2] or NULL                                      */
     float* dL_drotations; /* device [N,4] or NULL                                      */
     float* dL_dtransmat;  /* device [N,9] or NULL (when transmat_precomp was given)    */
+    float* dL_dshs_rest;  /* device [N,M-1,3] or NULL (when shs_rest was given)        */
 } GsrGrads;
 
 int32_t gsr_abi_version(void);

@@ -41,9 +41,9 @@ def test_abi_version_and_host_only_calls():
 def test_struct_layout_matches_header():
     # field order/size sanity: pointers are 8 bytes, struct sizes as the C compiler lays them out
     assert ctypes.sizeof(_lib.GsrView) == 4 * 9 + 4 + 8 * 4      # 9 scalars, pad, 4 pointers
-    assert ctypes.sizeof(_lib.GsrGaussians) == 8 + 8 * 7
+    assert ctypes.sizeof(_lib.GsrGaussians) == 8 + 8 * 8
     assert ctypes.sizeof(_lib.GsrForwardOut) == 8 * 3 + 8 + 8 * 3
-    assert ctypes.sizeof(_lib.GsrGrads) == 8 * 8
+    assert ctypes.sizeof(_lib.GsrGrads) == 8 * 9
 
 
 def test_operators_have_no_cpu_path():
