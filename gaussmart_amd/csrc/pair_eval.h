@@ -15,6 +15,10 @@ struct GsrPair {
 };
 
 // Returns false when the pair is skipped before the transmittance test.
+// The rare rejects (degenerate intersection, depth behind the near plane, positive power) are
+// folded into ONE predicate instead of early exits: on a wave that saves three exec-mask
+// save/branch/restore sequences per splat, and a lane that fails an early test is invalid whatever
+// garbage its later values hold, so the decisions are exactly those of the sequential tests.
 __device__ __forceinline__ bool gsr_pair_eval(float pxf, float pyf, const float4 a0, const float4 a1,
                                               const float4 a2, float opa, GsrPair& o) {
     const float Tux = a0.x, Tuy = a0.y, Tuz = a0.z, Tvx = a0.w, Tvy = a1.x, Tvz = a1.y;
@@ -24,7 +28,7 @@ __device__ __forceinline__ bool gsr_pair_eval(float pxf, float pyf, const float4
     const float ppx = fmaf(o.ky, o.lz, -(o.kz * o.ly));
     const float ppy = fmaf(o.kz, o.lx, -(o.kx * o.lz));
     const float ppz = fmaf(o.kx, o.ly, -(o.ky * o.lx));
-    if (ppz == 0.0f) return false;
+    bool valid = ppz != 0.0f;
     o.inv_pz = gsr_rcp(ppz);
     o.sx = ppx * o.inv_pz; o.sy = ppy * o.inv_pz;
     const float rho3d = fmaf(o.sx, o.sx, o.sy * o.sy);
@@ -33,13 +37,13 @@ __device__ __forceinline__ bool gsr_pair_eval(float pxf, float pyf, const float4
     o.use3d = rho3d <= rho2d;
     const float rho = fminf(rho3d, rho2d);
     o.depth = o.use3d ? fmaf(o.sx, Twx, fmaf(o.sy, Twy, Twz)) : Twz;
-    if (o.depth < GSR_NEAR_N) return false;
+    valid = valid && !(o.depth < GSR_NEAR_N);
     const float power = -0.5f * rho;
-    if (power > 0.0f) return false;
+    valid = valid && !(power > 0.0f);
     o.G = __expf(power);
     o.araw = opa * o.G;
     o.alpha = fminf(GSR_ALPHA_MAX, o.araw);
-    return o.alpha >= GSR_ALPHA_MIN;
+    return valid && o.alpha >= GSR_ALPHA_MIN;
 }
 
 // distortion depth mapping m(z) and its derivative
