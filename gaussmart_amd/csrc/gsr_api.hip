@@ -159,19 +159,19 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     uint32_t* inst_begin = at<uint32_t>(geom, GL.inst_begin);
     uint32_t* depth_key = at<uint32_t>(geom, GL.depth_key);
 
-    // N-sized scratch: depth-sort double buffers, iota, offsets, sort + scan workspaces
+    // N-sized scratch: depth-sort double buffers, sort + scan workspaces
     const size_t nb = gsr_align(size_t(N > 0 ? N : 1) * 4);
     const size_t sort_ws_n = gsr_sort_ws_bytes(N);
     const size_t scan_ws_n = gsr_scan_workspace_bytes(N);
-    const size_t scratch_bytes = 4 * nb + gsr_align(size_t(N + 1) * 4) + sort_ws_n + scan_ws_n;
+    const size_t scratch_bytes = 3 * nb + sort_ws_n + scan_ws_n;
     char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, scratch_bytes));
     if (!scratch) { gsr_set_error("allocator returned NULL (scratch)"); return GSR_E_ALLOC; }
     uint32_t* keys_sorted = reinterpret_cast<uint32_t*>(scratch);
-    uint32_t* order = reinterpret_cast<uint32_t*>(scratch + nb);
-    uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(scratch + 2 * nb);
-    uint32_t* vals_tmp = reinterpret_cast<uint32_t*>(scratch + 3 * nb);
-    uint32_t* offs = reinterpret_cast<uint32_t*>(scratch + 4 * nb);
-    void* sort_ws = scratch + 4 * nb + gsr_align(size_t(N + 1) * 4);
+    uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(scratch + nb);
+    uint32_t* vals_tmp = reinterpret_cast<uint32_t*>(scratch + 2 * nb);
+    uint32_t* order = at<uint32_t>(geom, GL.order);     // kept for the backward's row reduction
+    uint32_t* offs = at<uint32_t>(geom, GL.offs);
+    void* sort_ws = scratch + 3 * nb;
     void* scan_ws = static_cast<char*>(sort_ws) + sort_ws_n;
 
     uint32_t D = 0;
@@ -249,14 +249,16 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     const GsrBinLayout BL(num_rendered, gx * gy);
     const GsrImageLayout IL((int64_t)W * H);
 
-    // 4 sub-rows (one per quad) of 80 bytes per instance + one flag byte per sub-row
+    // 4 sub-rows (one per quad) of 80 bytes per instance + one flag byte per sub-row + per-Gaussian sums
     const size_t n_inst = size_t(num_rendered > 0 ? num_rendered : 1);
     const size_t rows_bytes = gsr_align(n_inst * 4 * GSR_GROW_FLOATS * 4);
     const size_t flags_bytes = gsr_align(n_inst * 4);
-    char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, rows_bytes + flags_bytes));
+    const size_t sums_bytes = gsr_align(size_t(N > 0 ? N : 1) * GSR_GROW_FLOATS * 4);
+    char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, rows_bytes + flags_bytes + sums_bytes));
     if (!scratch) { gsr_set_error("allocator returned NULL (gradient rows)"); return GSR_E_ALLOC; }
     float* grad_rows = reinterpret_cast<float*>(scratch);
     uint8_t* row_flags = reinterpret_cast<uint8_t*>(scratch + rows_bytes);
+    float* row_sums = reinterpret_cast<float*>(scratch + rows_bytes + flags_bytes);
 
     if (num_rendered > 0) {
         GSR_HIP_CHECK(hipMemsetAsync(row_flags, 0, size_t(num_rendered) * 4, s));
@@ -271,9 +273,11 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     if (!g->colors_precomp) o.dL_dcolors = nullptr;
     if (!g->scales) { o.dL_dscales = nullptr; o.dL_drotations = nullptr; }
     if (!g->transmat_precomp) o.dL_dtransmat = nullptr;
+    rc = gsr_launch_reduce_rows(N, at<uint32_t>(geom, GL.order), at<uint32_t>(geom, GL.offs), grad_rows,
+                                reinterpret_cast<const uint32_t*>(row_flags), row_sums, s);
+    if (rc != GSR_OK) return rc;
     return gsr_launch_preprocess_bwd(*view, *g, radii, at<float>(geom, GL.splat), at<uint32_t>(geom, GL.clamped),
-                                     at<uint32_t>(geom, GL.tiles_touched), at<uint32_t>(geom, GL.inst_begin),
-                                     grad_rows, reinterpret_cast<const uint32_t*>(row_flags), o, s);
+                                     row_sums, o, s);
 }
 
 // ------------------------------------------------------------------------------- introspection
@@ -289,6 +293,8 @@ extern "C" int32_t gsr_buffer_field(int32_t which, const char* name, int32_t N, 
         if (!strcmp(name, "tiles_touched")) { *offset = L.tiles_touched; *bytes = size_t(N) * 4; return GSR_OK; }
         if (!strcmp(name, "inst_begin")) { *offset = L.inst_begin; *bytes = size_t(N) * 4; return GSR_OK; }
         if (!strcmp(name, "depth_key")) { *offset = L.depth_key; *bytes = size_t(N) * 4; return GSR_OK; }
+        if (!strcmp(name, "order")) { *offset = L.order; *bytes = size_t(N) * 4; return GSR_OK; }
+        if (!strcmp(name, "offs")) { *offset = L.offs; *bytes = size_t(N + 1) * 4; return GSR_OK; }
     } else if (which == GSR_BUF_BINNING) {
         const GsrBinLayout L(D, gx * gy);
         if (!strcmp(name, "point_list")) { *offset = L.point_list; *bytes = size_t(D) * 4; return GSR_OK; }

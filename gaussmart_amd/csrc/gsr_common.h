@@ -63,7 +63,7 @@ struct GsrProfileScope {
 static inline size_t gsr_align(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct GsrGeomLayout {
-    size_t splat, clamped, tiles_touched, inst_begin, depth_key, total;
+    size_t splat, clamped, tiles_touched, inst_begin, depth_key, order, offs, total;
     explicit GsrGeomLayout(int64_t N) {
         size_t o = 0;
         splat = o;         o += gsr_align(size_t(N) * GSR_SPLAT_FLOATS * 4);
@@ -71,6 +71,8 @@ struct GsrGeomLayout {
         tiles_touched = o; o += gsr_align(size_t(N) * 4);
         inst_begin = o;    o += gsr_align(size_t(N) * 4);
         depth_key = o;     o += gsr_align(size_t(N) * 4);
+        order = o;         o += gsr_align(size_t(N) * 4);        // depth rank -> Gaussian id
+        offs = o;          o += gsr_align(size_t(N + 1) * 4);    // depth rank -> first instance (emission order)
         total = o > 0 ? o : 256;
     }
 };
@@ -127,10 +129,10 @@ int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32
                           const float* stream, const float* final_T, const uint32_t* n_contrib,
                           const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
                           uint8_t* row_flags, hipStream_t s);
+int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* offs, const float* grad_rows,
+                           const uint32_t* row_flags, float* row_sums, hipStream_t s);
 int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int32_t* radii,
-                              const float* splat, const uint32_t* clamped,
-                              const uint32_t* tiles_touched, const uint32_t* inst_begin,
-                              const float* grad_rows, const uint32_t* row_flags,
+                              const float* splat, const uint32_t* clamped, const float* row_sums,
                               const GsrGrads& out, hipStream_t s);
 
 // ---------------------------------------------------------------- small device helpers

@@ -1,6 +1,9 @@
-// K8 preprocess_bwd: one thread per Gaussian.
-//   1. sum this Gaussian's flagged per-(instance, quad) gradient sub-rows (contiguous: rows are in
-//      emission order) in a fixed order,
+// K8 preprocess_bwd, two launches:
+//   reduce_rows : 5 threads per Gaussian IN DEPTH-RANK ORDER (so the instance rows are swept almost
+//      sequentially) add its flagged per-(instance, quad) gradient sub-rows in a fixed order, one
+//      16-byte piece per thread, and scatter the 80-byte sum to the Gaussian's id;
+//   preprocess_bwd : one thread per Gaussian, id order:
+//   1. read its 80-byte row sum,
 //   2. densification statistic for means2D.grad (consumer scene/gaussian_model.py:551-553),
 //   3. chain rule  AABB centre -> T,  T -> (mean3D, scale, quaternion),  normal -> quaternion,
 //   4. SH backward (clamp mask, view-direction term into mean3D).
@@ -21,9 +24,43 @@ struct PreBwdParams {
     const float* means; const float* shs; const float* shs_rest; const float* opac; const float* scales; const float* rots;
     const float* tprecomp;
     const int32_t* radii; const float* splat; const uint32_t* clamped;
-    const uint32_t* tiles; const uint32_t* inst_begin; const float* grad_rows; const uint32_t* row_flags;
+    const float* row_sums;
     GsrGrads out;
 };
+
+__global__ void __launch_bounds__(256) reduce_rows_kernel(long long n_threads, const uint32_t* __restrict__ order,
+                                                          const uint32_t* __restrict__ offs,
+                                                          const float4* __restrict__ rows,
+                                                          const uint32_t* __restrict__ flags,
+                                                          float4* __restrict__ sums) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_threads) return;
+    const int r = (int)(t / 5), q = (int)(t - (long long)r * 5);
+    const uint32_t e0 = offs[r], e1 = offs[r + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t e = e0; e < e1; ++e) {
+        const uint32_t f = flags[e];                 // four byte flags: which quads wrote a sub-row
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            if ((f >> (8 * sub)) & 0xFFu) {
+                const float4 v = rows[((size_t)e * 4 + sub) * 5 + q];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+    }
+    sums[(size_t)order[r] * 5 + q] = acc;
+}
+
+int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* offs, const float* grad_rows,
+                           const uint32_t* row_flags, float* row_sums, hipStream_t s) {
+    if (N <= 0) return GSR_OK;
+    GsrProfileScope prof(GSR_K_PREPROCESS_BWD, s);
+    const long long n_threads = (long long)N * 5;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, s, n_threads, order, offs,
+                       reinterpret_cast<const float4*>(grad_rows), row_flags, reinterpret_cast<float4*>(row_sums));
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}
 
 template <bool STAGE_SH>
 __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p) {
@@ -53,24 +90,12 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
     float Tu[3], Tv[3], Tw[3];
     if (visible) {
         // ---- 1. instance rows ---------------------------------------------------------------
-        const uint32_t b = p.inst_begin[idx], cnt = p.tiles[idx];
         float acc[20];
+        const float4* rs = reinterpret_cast<const float4*>(p.row_sums + (size_t)idx * GSR_GROW_FLOATS);
 #pragma unroll
-        for (int k = 0; k < 20; ++k) acc[k] = 0.f;
-        // 4 sub-rows per instance (one per 8x8 quad of the tile); only the flagged ones were written
-        const float4* rows = reinterpret_cast<const float4*>(p.grad_rows + (size_t)b * 4 * GSR_GROW_FLOATS);
-        for (uint32_t e = 0; e < cnt; ++e) {
-            const uint32_t f = p.row_flags[b + e];       // 4 byte flags
-#pragma unroll
-            for (int sub = 0; sub < 4; ++sub) {
-                if ((f >> (8 * sub)) & 0xFFu) {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) {
-                        const float4 v = rows[((size_t)e * 4 + sub) * 5 + q];
-                        acc[4 * q + 0] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
-                    }
-                }
-            }
+        for (int q = 0; q < 5; ++q) {
+            const float4 v = rs[q];
+            acc[4 * q + 0] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) dT[k] = acc[GSR_GR_T + k];
@@ -292,9 +317,7 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
 
 int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int32_t* radii,
                               const float* splat, const uint32_t* clamped,
-                              const uint32_t* tiles_touched, const uint32_t* inst_begin,
-                              const float* grad_rows, const uint32_t* row_flags, const GsrGrads& out,
-                              hipStream_t s) {
+                              const float* row_sums, const GsrGrads& out, hipStream_t s) {
     if (g.count <= 0) return GSR_OK;
     PreBwdParams p;
     p.N = g.count; p.W = v.width; p.H = v.height; p.deg = v.sh_degree; p.M = v.sh_coeffs;
@@ -302,7 +325,7 @@ int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int
     p.raw = (v.flags & (uint32_t)GSR_FLAG_RAW_PARAMS) != 0;
     p.means = g.means3D; p.shs = g.shs; p.shs_rest = g.shs_rest; p.opac = g.opacities; p.scales = g.scales; p.rots = g.rotations;
     p.tprecomp = g.transmat_precomp; p.radii = radii; p.splat = splat; p.clamped = clamped;
-    p.tiles = tiles_touched; p.inst_begin = inst_begin; p.grad_rows = grad_rows; p.row_flags = row_flags; p.out = out;
+    p.row_sums = row_sums; p.out = out;
     const int blocks = (g.count + PB_BLOCK - 1) / PB_BLOCK;
     GsrProfileScope prof(GSR_K_PREPROCESS_BWD, s);
     const bool stage = sh_can_stage(g.shs, g.shs_rest, v.sh_coeffs) && sh_can_stage(out.dL_dshs, out.dL_dshs_rest, v.sh_coeffs);
