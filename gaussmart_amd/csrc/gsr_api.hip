@@ -224,7 +224,8 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     }
 
     return gsr_launch_render_fwd(*view, ranges, at<float>(binning, BL.stream), at<float>(image, IL.final_T),
-                                 at<uint32_t>(image, IL.n_contrib), out->out_color, out->out_allmap, s);
+                                 at<uint32_t>(image, IL.n_contrib), out->out_color, out->out_allmap,
+                                 at<uint8_t>(binning, BL.touch), s);
 }
 
 // ------------------------------------------------------------------------------- backward
@@ -263,7 +264,7 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     if (num_rendered > 0) {
         GSR_HIP_CHECK(hipMemsetAsync(row_flags, 0, size_t(num_rendered) * 4, s));
         rc = gsr_launch_render_bwd(*view, at<uint32_t>(binning, BL.ranges), at<uint32_t>(binning, BL.inst_row),
-                                   at<float>(binning, BL.stream), at<float>(image, IL.final_T),
+                                   at<float>(binning, BL.stream), at<uint8_t>(binning, BL.touch), at<float>(image, IL.final_T),
                                    at<uint32_t>(image, IL.n_contrib), dL_dcolor, dL_dallmap, grad_rows, row_flags, s);
         if (rc != GSR_OK) return rc;
     }

@@ -77,7 +77,7 @@ struct GsrGeomLayout {
     }
 };
 struct GsrBinLayout {
-    size_t point_list, inst_row, ranges, stream, total;
+    size_t point_list, inst_row, ranges, stream, touch, total;
     GsrBinLayout(int64_t D, int64_t tiles) {
         size_t o = 0;
         point_list = o; o += gsr_align(size_t(D) * 4);
@@ -86,6 +86,9 @@ struct GsrBinLayout {
         // splat records copied into (tile, depth) order: the render kernels stream them with
         // coalesced loads instead of gathering 80-byte records by Gaussian id twice per iteration
         stream = o;     o += gsr_align(size_t(D) * GSR_SPLAT_FLOATS * 4);
+        // one byte per (sorted instance, quad): did the forward blend it into >= 1 pixel of that quad?
+        // The backward evaluates exactly those pairs (everything else has zero gradient).
+        touch = o;      o += gsr_align(size_t(D) * 4);
         total = o > 0 ? o : 256;
     }
 };
@@ -124,9 +127,9 @@ int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorte
                              float* stream, hipStream_t s);
 int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* stream,
                           float* final_T, uint32_t* n_contrib, float* out_color,
-                          float* out_allmap, hipStream_t s);
+                          float* out_allmap, uint8_t* touch, hipStream_t s);
 int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* inst_row,
-                          const float* stream, const float* final_T, const uint32_t* n_contrib,
+                          const float* stream, const uint8_t* touch, const float* final_T, const uint32_t* n_contrib,
                           const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
                           uint8_t* row_flags, hipStream_t s);
 int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* offs, const float* grad_rows,

@@ -9,7 +9,8 @@
 //   * it starts at the deepest list entry ANY OF ITS 64 PIXELS reached (quad-level, not tile-level)
 //     and streams the (tile, depth)-ordered splat records backwards, 64 per batch, coalesced, into
 //     its private LDS slice while the next batch is prefetched into registers;
-//   * a 64-bit ballot of "cull rect overlaps my quad" selects the splats it evaluates at all;
+//   * a 64-bit ballot of the forward's "blended into >= 1 pixel of this quad" bytes selects EXACTLY
+//     the splats that carry gradient here; nothing else is even evaluated;
 //   * the suffix recursions of colour, depth, alpha and normal are collapsed into ONE scalar
 //     recursion (they are linear: q_i = c_i.dL/dC + z_i dL/dD + dL/dA + n_i.dL/dN);
 //   * the 18 partial derivatives are summed over the 64 pixels with the transposed butterfly below
@@ -41,7 +42,7 @@ struct RenderBwdParams {
     int W, H, gx;
     uint32_t flags;
     const uint32_t* ranges; const uint32_t* inst_row;
-    const float4* stream; const float* bg;
+    const float4* stream; const uint8_t* touch; const float* bg;
     const float* final_T; const uint32_t* n_contrib;
     const float* dL_dcolor; const float* dL_dallmap;
     float* grad_rows; uint8_t* row_flags;
@@ -156,7 +157,8 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
     float last_alpha = 0.f, last_q = 0.f, acc_q = 0.f, last_dL_dT = 0.f;
 
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 pf0, pf1, pf2, pf3, pf4;   // named (not an array): keeps the prefetch in VGPRs, not scratch
+    float4 pf0, pf1, pf2, pf3, pf4;
+    uint32_t pf_touch = 0;   // named (not an array): keeps the prefetch in VGPRs, not scratch
     uint32_t pf_row = 0;
     int hi = max_contrib;
     {
@@ -164,27 +166,26 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
         const float4* src = p.stream + (size_t)(r0 + lo) * 5;
 GSR_LOAD5(src, cnt * 5);
         pf_row = lane < cnt ? p.inst_row[r0 + lo + lane] : 0u;
+        pf_touch = lane < cnt ? p.touch[((size_t)r0 + lo + lane) * 4 + wave] : 0u;
     }
 
     while (hi > 0) {
         const int lo = max(0, hi - 64), nb = hi - lo;
 s_rec[lane] = pf0; s_rec[64 + lane] = pf1; s_rec[128 + lane] = pf2; s_rec[192 + lane] = pf3; s_rec[256 + lane] = pf4;
         const uint32_t row_of_lane = pf_row;          // emission index of staged entry `lane`
+        const uint32_t touch_of_lane = pf_touch;      // did the forward blend staged entry `lane` in this quad?
         {   // prefetch the next (shallower) batch
             const int hi2 = lo, lo2 = max(0, hi2 - 64), cnt = hi2 - lo2;
             const float4* src = p.stream + (size_t)(r0 + lo2) * 5;
 GSR_LOAD5(src, cnt * 5);
             pf_row = lane < cnt ? p.inst_row[r0 + lo2 + lane] : 0u;
+            pf_touch = lane < cnt ? p.touch[((size_t)r0 + lo2 + lane) * 4 + wave] : 0u;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        // which staged splats can reach alpha >= 1/255 inside this wave's 8x8 quad at all?
-        bool ov = false;
-        if (lane < nb) {
-            const float4 r4 = s_rec[lane * 5 + 4];
-            ov = no_cull || gsr_rect_overlaps_quad(__float_as_uint(r4.z), __float_as_uint(r4.w), qx0, qy0);
-        }
+        // only the splats the forward blended into >= 1 pixel of this quad carry any gradient
+        const bool ov = lane < nb && (no_cull || touch_of_lane != 0u);
         unsigned long long todo_mask = __ballot(ov);
         while (todo_mask) {
             const int j = 63 - __builtin_clzll(todo_mask);      // deepest first
@@ -283,14 +284,14 @@ GSR_LOAD5(src, cnt * 5);
 }
 
 int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* inst_row,
-                          const float* stream, const float* final_T, const uint32_t* n_contrib,
+                          const float* stream, const uint8_t* touch, const float* final_T, const uint32_t* n_contrib,
                           const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
                           uint8_t* row_flags, hipStream_t s) {
     RenderBwdParams p;
     p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
     p.flags = v.flags;
-    p.ranges = ranges; p.inst_row = inst_row; p.stream = reinterpret_cast<const float4*>(stream); p.bg = v.bg;
+    p.ranges = ranges; p.inst_row = inst_row; p.stream = reinterpret_cast<const float4*>(stream); p.touch = touch; p.bg = v.bg;
     p.final_T = final_T; p.n_contrib = n_contrib; p.dL_dcolor = dL_dcolor; p.dL_dallmap = dL_dallmap;
     p.grad_rows = grad_rows; p.row_flags = row_flags;
     if (p.gx <= 0 || gy <= 0) return GSR_OK;

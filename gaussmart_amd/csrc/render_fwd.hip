@@ -11,7 +11,9 @@
 //   * each lane tests ONE staged splat's cull rect against the wave's quad; the 64-bit ballot is the
 //     list of splats the wave has to look at at all (iterated with s_ff1), the rest cost nothing;
 //   * per surviving splat the record is read with wave-uniform (broadcast) ds_read_b128;
-//   * the wave leaves as soon as ITS 64 pixels are done (quad-level early termination).
+//   * the wave leaves as soon as ITS 64 pixels are done (quad-level early termination);
+//   * per (instance, quad) it records one byte: "blended into at least one pixel" -- the exact set of
+//     pairs the backward has to evaluate.
 #include "gsr_common.h"
 #include "pair_eval.h"
 
@@ -36,6 +38,7 @@ struct RenderFwdParams {
     const uint32_t* ranges; const float4* stream;
     const float* bg;
     float* final_T; uint32_t* n_contrib; float* out_color; float* out_allmap;
+    uint8_t* touch;
 };
 
 #ifndef RF_MIN_WAVES
@@ -96,6 +99,7 @@ GSR_LOAD5(s2, lim);
             ov = no_cull || gsr_rect_overlaps_quad(__float_as_uint(r4.z), __float_as_uint(r4.w), qx0, qy0);
         }
         unsigned long long m = __ballot(ov);
+        uint32_t mine_lo = 0u, mine_hi = 0u;   // staged splats THIS pixel blends (bit j)
         while (m) {
             // every lane is active here (the loop is wave-uniform), so the vote sees the whole wave
             if (__all(done)) break;
@@ -124,6 +128,19 @@ GSR_LOAD5(s2, lim);
             C0 += a3.w * w; C1 += a4.x * w; C2 += a4.y * w;
             T = test_T;
             last_contributor = contributor;
+            const unsigned long long bit = 1ull << j;          // wave-uniform (scalar shift)
+            mine_lo |= (uint32_t)bit; mine_hi |= (uint32_t)(bit >> 32);
+        }
+        // OR over the 64 pixels, once per batch: which staged splats did this quad blend at all?
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            mine_lo |= (uint32_t)__shfl_xor((int)mine_lo, d, 64);
+            mine_hi |= (uint32_t)__shfl_xor((int)mine_hi, d, 64);
+        }
+        // one byte per (instance, quad) for the backward: lane j reports staged splat j
+        if (lane < nb) {
+            const uint32_t word = lane < 32 ? mine_lo : mine_hi;
+            p.touch[((size_t)r0 + base + lane) * 4 + wave] = (uint8_t)((word >> (lane & 31)) & 1u);
         }
         __builtin_amdgcn_wave_barrier();   // all reads of this batch precede the next batch's LDS writes
     }
@@ -149,12 +166,13 @@ GSR_LOAD5(s2, lim);
 
 int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* stream,
                           float* final_T, uint32_t* n_contrib, float* out_color,
-                          float* out_allmap, hipStream_t s) {
+                          float* out_allmap, uint8_t* touch, hipStream_t s) {
     RenderFwdParams p;
     p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE; p.flags = v.flags;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
     p.ranges = ranges; p.stream = reinterpret_cast<const float4*>(stream); p.bg = v.bg;
     p.final_T = final_T; p.n_contrib = n_contrib; p.out_color = out_color; p.out_allmap = out_allmap;
+    p.touch = touch;
     if (p.gx <= 0 || gy <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_RENDER_FWD, s);
     hipLaunchKernelGGL(render_fwd_kernel, dim3(p.gx, gy), dim3(RF_BLOCK), 0, s, p);

@@ -62,54 +62,124 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-_WORKSPACE = {}   # (device, stream, which) -> grow-only scratch buffer
-
-
 def _round_up(n, q):
     return (int(n) + q - 1) // q * q
 
 
-class _Allocator:
-    """Hands torch-owned device memory to the library (include/gsr.h: gsr_alloc_fn).
+class _BufferPool:
+    """Grow-only pool of the byte buffers the library asks for (include/gsr.h: gsr_alloc_fn).
 
-    Scratch buffers (only live inside one library call) come from a grow-only per-(device, stream)
-    workspace with 25 % headroom: their size follows the instance count D, which drifts every
-    iteration, and re-requesting ever slightly larger 1 GB blocks from the caching allocator means
-    hipMalloc calls (each a device synchronisation) in the middle of the training loop.  Buffers the
-    backward needs later (geom / binning / image) are ordinary tensors, rounded up to 32 MiB so the
-    caching allocator sees few distinct sizes."""
+    Their sizes follow the instance count D, which drifts by a fraction of a percent every
+    iteration.  Handing such requests to the caching allocator directly makes it hipMalloc a
+    slightly larger block every few iterations (each one a device synchronisation, and the smaller
+    block stays cached forever): the loop stalls and reserved memory creeps up.  The pool keeps the
+    buffers it ever created, per (device, stream, kind), with 25 % headroom, and leases them out:
+      * scratch kinds are only live inside one library call -> released when the call returns;
+      * geom / binning / image are needed by the backward -> released when the autograd node that
+        holds the lease dies (after backward, or when the outputs are dropped).
+    All leases of one pool key are used on one stream, so reuse is ordered by the stream."""
+
+    def __init__(self):
+        self.free = {}      # key -> list of tensors
+
+    def take(self, key, nbytes, device):
+        lst = self.free.setdefault(key, [])
+        best = None
+        for i, t in enumerate(lst):
+            if t.numel() >= nbytes and (best is None or t.numel() < lst[best].numel()):
+                best = i
+        if best is not None:
+            return lst.pop(best)
+        if lst:                                   # too small: let the largest one go, grow once
+            lst.sort(key=lambda t: t.numel())
+            lst.pop()
+        if _POOL_DEBUG:
+            print(f"[gsr pool] new buffer kind {key[2]}: need {nbytes / 2**20:.1f} MiB (had {[round(t.numel() / 2**20, 1) for t in lst]})", flush=True)
+        return torch.empty(_round_up(nbytes + nbytes // 4, 1 << 22), dtype=torch.uint8, device=device)
+
+    def give(self, key, t):
+        self.free.setdefault(key, []).append(t)
+
+    def clear(self):
+        self.free.clear()
+
+
+_POOL = _BufferPool()
+_POOL_DEBUG = bool(__import__("os").environ.get("GSR_POOL_DEBUG"))
+
+
+class _Lease:
+    """Buffers of one forward call; returns them to the pool when garbage collected."""
+
+    def __init__(self):
+        self.items = []     # (key, tensor)
+        self.released = False
+
+    def release(self):
+        for key, t in self.items:
+            _POOL.give(key, t)
+        self.items = []
+        self.released = True
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class _Allocator:
+    """Adapter between gsr_alloc_fn and the pool for ONE library call."""
 
     def __init__(self, device):
         self.device = device
         self.buffers = {}
         self.error = None
         self.stream = torch.cuda.current_stream(device).cuda_stream
+        self.kept = _Lease()        # geom / binning / image: travel with the autograd node
+        self.scratch = _Lease()     # released by done()
         self.cb = _lib.ALLOC_FN(self._alloc)
 
     def _alloc(self, _ctx, which, nbytes):
         try:
             which, nbytes = int(which), max(int(nbytes), 1)
-            if which in (_lib.GSR_BUF_SCRATCH, _lib.GSR_BUF_SCRATCH2):
-                key = (self.device, self.stream, which)
-                t = _WORKSPACE.get(key)
-                if t is None or t.numel() < nbytes:
-                    _WORKSPACE.pop(key, None)
-                    t = None
-                    t = torch.empty(_round_up(nbytes + nbytes // 4, 1 << 25), dtype=torch.uint8, device=self.device)
-                    _WORKSPACE[key] = t
-            else:
-                t = torch.empty(_round_up(nbytes, 1 << 25) if nbytes > (1 << 25) else nbytes, dtype=torch.uint8,
-                                device=self.device)
+            key = (self.device, self.stream, which)
+            t = _POOL.take(key, nbytes, self.device)
+            lease = self.scratch if which in (_lib.GSR_BUF_SCRATCH, _lib.GSR_BUF_SCRATCH2) else self.kept
+            lease.items.append((key, t))
             self.buffers[which] = t
             return t.data_ptr()
         except Exception as e:  # surfaces as GSR_E_ALLOC
             self.error = e
             return 0
 
+    def done(self):
+        """The library call has returned: its scratch may be reused by the next call on this stream."""
+        self.scratch.release()
+
+
+# Set to True to backpropagate through one forward more than once (retain_graph=True): the buffers the
+# forward saved then stay leased until the autograd node is garbage collected instead of going back
+# to the pool right after the first backward.
+KEEP_BUFFERS_AFTER_BACKWARD = False
+
+
+def _check_lease(ctx):
+    if ctx.lease.released:
+        raise _lib.GsrError("the buffers saved by this forward were recycled after its first backward; set "
+                            "gaussmart_amd.rasterizer.KEEP_BUFFERS_AFTER_BACKWARD = True to backpropagate twice")
+
+
+def _finish_lease(ctx):
+    # the autograd node often outlives backward() by several iterations (reference cycles through
+    # retain_grad hooks are only broken by the cyclic GC), so the lease is returned here
+    if not KEEP_BUFFERS_AFTER_BACKWARD:
+        ctx.lease.release()
+
 
 def release_workspace():
-    """Drop the cached scratch buffers (e.g. before handing the GPU to something else)."""
-    _WORKSPACE.clear()
+    """Drop every cached library buffer (e.g. before handing the GPU to something else)."""
+    _POOL.clear()
 
 
 def _make_view(rs: GaussianRasterizationSettings, sh_coeffs: int, flags: int, device):
@@ -159,10 +229,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             alloc = _Allocator(device)
             stream = torch.cuda.current_stream(device).cuda_stream
             rc = L.gsr_forward(C.byref(view), C.byref(g), C.byref(out), alloc.cb, None, C.c_void_p(stream))
+            alloc.done()
             if rc != 0 and alloc.error is not None:
                 raise alloc.error
             _lib.check(rc)
 
+        ctx.lease = alloc.kept          # geom / binning / image go back to the pool with this node
         ctx.raster_settings = rs
         ctx.flags = flags
         ctx.num_rendered = int(out.num_rendered)
@@ -184,6 +256,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, _grad_radii, grad_allmap):
         L = _lib.lib()
+        _check_lease(ctx)
         (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom,
          binning, image) = ctx.saved_tensors
         no_sh, no_col, no_sr, no_cov = ctx.none_mask
@@ -220,10 +293,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             rc = L.gsr_backward(C.byref(view), C.byref(g), ctx.num_rendered, _ptr(radii), _ptr(geom),
                                 _ptr(binning), _ptr(image), _ptr(grad_color), _ptr(grad_allmap),
                                 C.byref(grads), alloc.cb, None, C.c_void_p(stream))
+            alloc.done()
             if rc != 0 and alloc.error is not None:
                 raise alloc.error
             _lib.check(rc)
         del keep
+        _finish_lease(ctx)
         return (d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, None)
 
 
@@ -261,9 +336,11 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             alloc = _Allocator(device)
             stream = torch.cuda.current_stream(device).cuda_stream
             rc = L.gsr_forward(C.byref(view), C.byref(g), C.byref(out), alloc.cb, None, C.c_void_p(stream))
+            alloc.done()
             if rc != 0 and alloc.error is not None:
                 raise alloc.error
             _lib.check(rc)
+        ctx.lease = alloc.kept
         ctx.raster_settings, ctx.flags, ctx.num_rendered, ctx.M = rs, flags, int(out.num_rendered), M
         ctx.save_for_backward(xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, radii,
                               alloc.buffers[_lib.GSR_BUF_GEOM], alloc.buffers[_lib.GSR_BUF_BINNING],
@@ -275,6 +352,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, _grad_radii, grad_allmap):
         L = _lib.lib()
+        _check_lease(ctx)
         xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, radii, geom, binning, image = ctx.saved_tensors
         rs = ctx.raster_settings
         device = xyz.device
@@ -297,10 +375,12 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             rc = L.gsr_backward(C.byref(view), C.byref(g), ctx.num_rendered, _ptr(radii), _ptr(geom), _ptr(binning),
                                 _ptr(image), _ptr(grad_color), _ptr(grad_allmap), C.byref(grads), alloc.cb, None,
                                 C.c_void_p(stream))
+            alloc.done()
             if rc != 0 and alloc.error is not None:
                 raise alloc.error
             _lib.check(rc)
         del keep
+        _finish_lease(ctx)
         return d_xyz, d_2d, d_dc, d_rest, d_op, d_sc, d_rot, None, None
 
 
@@ -370,7 +450,8 @@ def rasterize_debug(means3D, opacities, shs=None, colors_precomp=None, scales=No
         _lib.check(rc)
         torch.cuda.synchronize(device)
     D = int(out.num_rendered)
-    res = dict(color=color, allmap=allmap, radii=radii, num_rendered=D)
+    # the views below alias pooled buffers: the lease keeps them out of the pool while `res` lives
+    res = dict(color=color, allmap=allmap, radii=radii, num_rendered=D, _lease=alloc.kept)
     spec = {
         _lib.GSR_BUF_GEOM: [("splat", torch.float32, (N, 20)), ("clamped", torch.int32, (N,)),
                             ("tiles_touched", torch.int32, (N,)), ("inst_begin", torch.int32, (N,)),
