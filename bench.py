@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tiles", type=int, default=12)
+    ap.add_argument("--cpu-tiles", type=int, default=1600)   # ~20 % of the frame: 15-20 s of host work
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -225,7 +225,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             log(f"GPU part done ({out['value']:.2f} it/s, D={D}); timing the CPU oracle on {host_cores()} cores")
-            out["cpu_baseline"] = cpu_baseline(params, cam, args.cpu_tiles, 100_000, dbg, W, H)
+            out["cpu_baseline"] = cpu_baseline(params, cam, args.cpu_tiles, N, dbg, W, H)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
