@@ -183,8 +183,18 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         if (rc != GSR_OK) return rc;
         rc = gsr_exclusive_scan_u32(tiles_touched, order, offs, N, scan_ws, s);
         if (rc != GSR_OK) return rc;
-        GSR_HIP_CHECK(hipMemcpyAsync(&D, offs + N, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        GSR_HIP_CHECK(hipStreamSynchronize(s));   // the one permitted sync: D sizes the next buffers
+        // The instance count sizes the next buffers, so the host has to see it: the copy is followed by
+        // an event, and the SH colour pass is enqueued BEHIND that event so that it runs during the
+        // host round trip (wait on the event, allocate, launch) instead of leaving the GPU idle.
+        hipEvent_t ev;
+        GSR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e1 = hipMemcpyAsync(&D, offs + N, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        hipError_t e2 = e1 == hipSuccess ? hipEventRecord(ev, s) : e1;
+        rc = e2 == hipSuccess ? gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, s) : GSR_OK;
+        hipError_t e3 = e2 == hipSuccess ? hipEventSynchronize(ev) : e2;   // the one host wait of the forward
+        (void)hipEventDestroy(ev);
+        GSR_HIP_CHECK(e3);
+        if (rc != GSR_OK) return rc;
     }
     if (D > 0x7FFFFFF0u) { gsr_set_error("instance count %u overflows", D); return GSR_E_UNSUPPORTED; }
     out->num_rendered = (int32_t)D;

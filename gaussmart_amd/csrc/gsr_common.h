@@ -117,6 +117,8 @@ int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint3
 int gsr_launch_preprocess_fwd(const GsrView& v, const GsrGaussians& g, float* splat,
                               uint32_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key,
                               int32_t* radii, hipStream_t s);
+int gsr_launch_preprocess_color(const GsrView& v, const GsrGaussians& g, float* splat, uint32_t* clamped,
+                                int32_t* radii, hipStream_t s);
 int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const uint32_t* offs,
                     const float* splat, const int32_t* radii, const uint32_t* tiles_touched,
                     uint32_t* inst_begin, uint32_t* tile_keys, uint32_t* inst_vals,

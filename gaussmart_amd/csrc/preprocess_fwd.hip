@@ -60,7 +60,10 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, const float* sh /*[M][3] in
     return make_float3(r[0], r[1], r[2]);
 }
 
-template <bool STAGE_SH>
+// WITH_SH: evaluate the SH colour in this kernel (single-launch form).  The library normally runs
+// the geometry part first and the colour part (preprocess_color_kernel) later, so that the colour
+// evaluation overlaps the host round trip that fetches the instance count.
+template <bool STAGE_SH, bool WITH_SH>
 __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -69,7 +72,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
     const int wave_first = blockIdx.x * PRE_BLOCK + wave * 64;
 
     float* my_sh = nullptr;
-    if (STAGE_SH) {
+    if (STAGE_SH && WITH_SH) {
         // cooperative, fully coalesced fetch of this wave's 64 SH blocks (wave-private LDS region:
         // LDS ops of one wave complete in order, no workgroup barrier needed)
         float* wl = lds + wave * 64 * SH_ROW_FLOATS;
@@ -156,14 +159,14 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
     if (ntiles == 0) return;
 
     uint32_t clamp_bits = 0;
-    float3 rgb;
-    if (p.colors == nullptr) {
+    float3 rgb = make_float3(0.f, 0.f, 0.f);
+    if (p.colors == nullptr && WITH_SH) {
         float dx = px - p.campos[0], dy = py - p.campos[1], dz = pz - p.campos[2];
         const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
         const float3 dir = make_float3(dx * il, dy * il, dz * il);
         if (STAGE_SH) rgb = sh_to_rgb(p.deg, my_sh, 3, dir, clamp_bits);
         else          rgb = sh_to_rgb(p.deg, p.shs + (size_t)idx * p.M * 3, 3, dir, clamp_bits);
-    } else {
+    } else if (p.colors != nullptr) {
         rgb = make_float3(p.colors[3 * idx], p.colors[3 * idx + 1], p.colors[3 * idx + 2]);
     }
 
@@ -218,11 +221,37 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
     p.dkey[idx] = __float_as_uint(vz);
 }
 
-int gsr_launch_preprocess_fwd(const GsrView& v, const GsrGaussians& g, float* splat,
-                              uint32_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key,
-                              int32_t* radii, hipStream_t s) {
-    if (g.count <= 0) return GSR_OK;
-    PreParams p;
+// Colour part of K1: SH -> RGB (+0.5, clamp at 0, clamp mask) for the Gaussians that survived the
+// culls, written into their splat record.  Runs after the binning front end has been enqueued.
+template <bool STAGE_SH>
+__global__ void __launch_bounds__(PRE_BLOCK) preprocess_color_kernel(PreParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int idx = blockIdx.x * PRE_BLOCK + tid;
+    const int wave_first = blockIdx.x * PRE_BLOCK + wave * 64;
+    float* my_sh = nullptr;
+    if (STAGE_SH) {
+        float* wl = lds + wave * 64 * SH_ROW_FLOATS;
+        sh_stage<true>(wl, const_cast<float*>(p.shs), const_cast<float*>(p.shs_rest), p.M, wave_first,
+                       min(64, p.N - wave_first), lane);
+        my_sh = wl + lane * SH_ROW_FLOATS;
+    }
+    if (idx >= p.N || p.radii[idx] <= 0) return;
+    const float dx = p.means[3 * idx + 0] - p.campos[0], dy = p.means[3 * idx + 1] - p.campos[1],
+                dz = p.means[3 * idx + 2] - p.campos[2];
+    const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    const float3 dir = make_float3(dx * il, dy * il, dz * il);
+    uint32_t clamp_bits = 0;
+    const float3 rgb = STAGE_SH ? sh_to_rgb(p.deg, my_sh, 3, dir, clamp_bits)
+                                : sh_to_rgb(p.deg, p.shs + (size_t)idx * p.M * 3, 3, dir, clamp_bits);
+    float* rec = p.splat + (size_t)idx * GSR_SPLAT_FLOATS;
+    rec[GSR_SP_RGB] = rgb.x; rec[GSR_SP_RGB + 1] = rgb.y; rec[GSR_SP_RGB + 2] = rgb.z;
+    p.clamped[idx] = clamp_bits;
+}
+
+static void fill_pre_params(PreParams& p, const GsrView& v, const GsrGaussians& g, float* splat, uint32_t* clamped,
+                            uint32_t* tiles_touched, uint32_t* depth_key, int32_t* radii) {
     p.N = g.count; p.W = v.width; p.H = v.height;
     p.gx = (v.width + GSR_TILE - 1) / GSR_TILE; p.gy = (v.height + GSR_TILE - 1) / GSR_TILE;
     p.deg = v.sh_degree; p.M = v.sh_coeffs; p.mod = v.scale_modifier;
@@ -231,16 +260,37 @@ int gsr_launch_preprocess_fwd(const GsrView& v, const GsrGaussians& g, float* sp
     p.means = g.means3D; p.shs = g.shs; p.shs_rest = g.shs_rest; p.colors = g.colors_precomp; p.opac = g.opacities;
     p.scales = g.scales; p.rots = g.rotations; p.tprecomp = g.transmat_precomp;
     p.splat = splat; p.clamped = clamped; p.tiles = tiles_touched; p.dkey = depth_key; p.radii = radii;
+}
+
+int gsr_launch_preprocess_color(const GsrView& v, const GsrGaussians& g, float* splat, uint32_t* clamped,
+                                int32_t* radii, hipStream_t s) {
+    if (g.count <= 0 || g.shs == nullptr) return GSR_OK;
+    PreParams p;
+    fill_pre_params(p, v, g, splat, clamped, nullptr, nullptr, radii);
     const int blocks = (g.count + PRE_BLOCK - 1) / PRE_BLOCK;
     GsrProfileScope prof(GSR_K_PREPROCESS_FWD, s);
     const bool stage = sh_can_stage(g.shs, g.shs_rest, v.sh_coeffs);
     if (g.shs_rest && !stage) { gsr_set_error("split SH storage needs 16-byte aligned pointers and <= 16 coefficients"); return GSR_E_UNSUPPORTED; }
     if (stage) {
         const size_t lds_bytes = (size_t)(PRE_BLOCK / 64) * 64 * SH_ROW_FLOATS * sizeof(float);
-        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(blocks), dim3(PRE_BLOCK), lds_bytes, s, p);
+        hipLaunchKernelGGL(preprocess_color_kernel<true>, dim3(blocks), dim3(PRE_BLOCK), lds_bytes, s, p);
     } else {
-        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(blocks), dim3(PRE_BLOCK), 0, s, p);
+        hipLaunchKernelGGL(preprocess_color_kernel<false>, dim3(blocks), dim3(PRE_BLOCK), 0, s, p);
     }
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}
+
+// Geometry part of K1 (everything except the SH colour; precomputed colours are copied here).
+int gsr_launch_preprocess_fwd(const GsrView& v, const GsrGaussians& g, float* splat,
+                              uint32_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key,
+                              int32_t* radii, hipStream_t s) {
+    if (g.count <= 0) return GSR_OK;
+    PreParams p;
+    fill_pre_params(p, v, g, splat, clamped, tiles_touched, depth_key, radii);
+    const int blocks = (g.count + PRE_BLOCK - 1) / PRE_BLOCK;
+    GsrProfileScope prof(GSR_K_PREPROCESS_FWD, s);
+    hipLaunchKernelGGL((preprocess_fwd_kernel<false, false>), dim3(blocks), dim3(PRE_BLOCK), 0, s, p);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }
