@@ -48,18 +48,33 @@ __global__ void __launch_bounds__(256) loss_fwd_kernel(const float* __restrict__
     const size_t HW = (size_t)H * W;
     float ssim_acc = 0.f, l1_acc = 0.f;
 
-    for (int c = 0; c < C; ++c) {
+    // tile + halo of one channel = 676 values per image: 3 per thread (the last pass partly idle);
+    // the NEXT channel's values are fetched into registers while the current one is filtered
+    constexpr int LS_PER_THREAD = (LS_REG * LS_REG + 255) / 256;
+    float rx[LS_PER_THREAD], ry[LS_PER_THREAD];
+    auto fetch = [&](int c) {
         const float* xi = img + c * HW;
         const float* yi = gt + c * HW;
-        __syncthreads();
-        for (int i = threadIdx.x; i < LS_REG * LS_REG; i += 256) {
+#pragma unroll
+        for (int k = 0; k < LS_PER_THREAD; ++k) {
+            const int i = threadIdx.x + k * 256;
             const int r = i / LS_REG, q = i - r * LS_REG;
             const int gy = y0 + r - LS_HALO, gx = x0 + q - LS_HALO;
-            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            sx[r][q] = ok ? xi[(size_t)gy * W + gx] : 0.f;
-            sy[r][q] = ok ? yi[(size_t)gy * W + gx] : 0.f;
+            const bool ok = i < LS_REG * LS_REG && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            rx[k] = 0.f; ry[k] = 0.f;
+            if (ok) { rx[k] = xi[(size_t)gy * W + gx]; ry[k] = yi[(size_t)gy * W + gx]; }
+        }
+    };
+    fetch(0);
+    for (int c = 0; c < C; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LS_PER_THREAD; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < LS_REG * LS_REG) { const int r = i / LS_REG, q = i - r * LS_REG; sx[r][q] = rx[k]; sy[r][q] = ry[k]; }
         }
         __syncthreads();
+        if (c + 1 < C) fetch(c + 1);
         // horizontal pass: 26 rows x 16 columns
         for (int i = threadIdx.x; i < LS_REG * LS_TILE; i += 256) {
             const int r = i / LS_TILE, q = i - r * LS_TILE;
@@ -121,17 +136,33 @@ __global__ void __launch_bounds__(256) loss_bwd_kernel(const float* __restrict__
     const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
     const float k_ssim = -lambda * inv_n * gs, k_l1 = (1.0f - lambda) * inv_n * gs;
 
-    for (int c = 0; c < C; ++c) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < LS_REG * LS_REG; i += 256) {
+    constexpr int LS_PER_THREAD = (LS_REG * LS_REG + 255) / 256;
+    float rm[3][LS_PER_THREAD];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < LS_PER_THREAD; ++k) {
+            const int i = threadIdx.x + k * 256;
             const int r = i / LS_REG, q = i - r * LS_REG;
             const int gy = y0 + r - LS_HALO, gx = x0 + q - LS_HALO;
-            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const bool ok = i < LS_REG * LS_REG && gy >= 0 && gy < H && gx >= 0 && gx < W;
             const size_t o = (size_t)gy * W + gx;
 #pragma unroll
-            for (int m = 0; m < 3; ++m) sm[m][r][q] = ok ? maps[(size_t)(m * C + c) * HW + o] : 0.f;
+            for (int m = 0; m < 3; ++m) { rm[m][k] = 0.f; if (ok) rm[m][k] = maps[(size_t)(m * C + c) * HW + o]; }
+        }
+    };
+    fetch(0);
+    for (int c = 0; c < C; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LS_PER_THREAD; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < LS_REG * LS_REG) {
+                const int r = i / LS_REG, q = i - r * LS_REG;
+                sm[0][r][q] = rm[0][k]; sm[1][r][q] = rm[1][k]; sm[2][r][q] = rm[2][k];
+            }
         }
         __syncthreads();
+        if (c + 1 < C) fetch(c + 1);
         for (int i = threadIdx.x; i < LS_REG * LS_TILE; i += 256) {
             const int r = i / LS_TILE, q = i - r * LS_TILE;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
