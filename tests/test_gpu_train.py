@@ -131,3 +131,41 @@ def test_raw_parameter_path_equals_activated_path(gpu_device, sh_degree, active)
         assert float((ga - gb).abs().max()) <= 5e-3 * sc + 1e-12, (ga.shape, float((ga - gb).abs().max()), sc)
         assert float((ga - gb).abs().mean()) <= 1e-6 * sc + 1e-14
     torch.testing.assert_close(a[4], b[4], rtol=1e-4, atol=1e-4 * float(a[4].abs().max()))
+
+
+def test_train_cli_on_blender_style_scene(gpu_device, tmp_path):
+    """End to end through the CLI: synthetic transforms_*.json scene on disk -> Scene -> training with
+    densification -> PLY + checkpoint + results.json, PSNR reported."""
+    import json, os
+    import numpy as np
+    from PIL import Image
+    from gaussmart_amd import train_cli
+    from gaussmart_amd.gaussian_model import GaussianModel
+    from gaussmart_amd.gaussian_renderer import render
+    from gaussmart_amd.params import PipelineParams
+    from gaussmart_amd.synthetic import make_scene, jittered_cameras
+    root, out = tmp_path / "scene", tmp_path / "out"
+    os.makedirs(root / "train"); os.makedirs(root / "test")
+    W, H = 160, 120
+    params, _ = make_scene(4000, W, H, seed=3, radius_px=5.0)
+    cams = jittered_cameras(8, W, H, seed=3, device=gpu_device, amount=0.2)
+    m = GaussianModel(3, device=gpu_device); m.create_from_params(params)
+    frames = {"train": [], "test": []}
+    for i, cam in enumerate(cams):
+        split = "test" if i % 4 == 0 else "train"
+        with torch.no_grad():
+            img = render(cam, m, PipelineParams(), torch.zeros(3, device=gpu_device), surface_maps=False)["render"].clamp(0, 1)
+        rgba = np.concatenate([(img.permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8), np.full((H, W, 1), 255, np.uint8)], -1)
+        Image.fromarray(rgba, "RGBA").save(root / split / f"r_{i}.png")
+        c2w = np.linalg.inv(cam.world_view_transform.T.cpu().numpy().astype(np.float64))
+        c2w[:3, 1:3] *= -1      # COLMAP axes -> Blender axes (the reader flips them back)
+        frames[split].append({"file_path": f"./{split}/r_{i}", "transform_matrix": c2w.tolist()})
+    for split in ("train", "test"):
+        json.dump({"camera_angle_x": cams[0].FoVx, "frames": frames[split]}, open(root / f"transforms_{split}.json", "w"))
+    # seed point cloud = the true centres, so 200 iterations are enough to see a sane PSNR
+    from gaussmart_amd.scene_io import storePly
+    storePly(str(root / "points3d.ply"), params["xyz"].numpy(), np.full((4000, 3), 128))
+    train_cli.main(["-s", str(root), "-m", str(out), "--iterations", "700", "--save_iterations", "700", "--eval", "--log_every", "0"])
+    res = json.load(open(out / "results.json"))
+    assert res["iterations"] == 700 and res["points"] > 0 and res["psnr_train"] > 15.0 and res["psnr_test"] > 12.0
+    assert os.path.exists(out / "point_cloud" / "iteration_700" / "point_cloud.ply") and os.path.exists(out / "chkpnt700.pth")
