@@ -95,7 +95,19 @@ static int validate(const GsrView* v, const GsrGaussians* g) {
     if (!v || !g) { gsr_set_error("null view / gaussians"); return GSR_E_INVALID; }
     if (v->width <= 0 || v->height <= 0) { gsr_set_error("bad image size %dx%d", v->width, v->height); return GSR_E_INVALID; }
     if (g->count < 0) { gsr_set_error("negative Gaussian count"); return GSR_E_INVALID; }
-    if (v->channels != 3) { gsr_set_error("channels=%d: only 3 colour channels are supported", v->channels); return GSR_E_UNSUPPORTED; }
+    // 3 channels (the reference's RGB) or a wide per-pixel payload: precomputed features, C = 4, 8, ... 64
+    if (v->channels != 3) {
+        const bool wide_ok = v->channels >= 4 && v->channels <= GSR_MAX_CHANNELS && (v->channels % 4) == 0;
+        if (!wide_ok || g->shs != nullptr || g->colors_precomp == nullptr) {
+            gsr_set_error("channels=%d: 3 channels, or 4..%d (multiple of 4) with colors_precomp, are supported",
+                          v->channels, GSR_MAX_CHANNELS);
+            return GSR_E_UNSUPPORTED;
+        }
+        if ((reinterpret_cast<uintptr_t>(g->colors_precomp) & 15u) != 0) {
+            gsr_set_error("wide colors_precomp must be 16-byte aligned");
+            return GSR_E_INVALID;
+        }
+    }
     if ((g->shs == nullptr) == (g->colors_precomp == nullptr)) {
         gsr_set_error("Please provide excatly one of either SHs or precomputed colors!");
         return GSR_E_INVALID;
@@ -235,7 +247,8 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
 
     return gsr_launch_render_fwd(*view, ranges, at<float>(binning, BL.stream), at<float>(image, IL.final_T),
                                  at<uint32_t>(image, IL.n_contrib), out->out_color, out->out_allmap,
-                                 at<uint8_t>(binning, BL.touch), s);
+                                 at<uint8_t>(binning, BL.touch), view->channels == 3 ? nullptr : g->colors_precomp,
+                                 point_list, s);
 }
 
 // ------------------------------------------------------------------------------- backward
@@ -265,8 +278,11 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     const size_t rows_bytes = gsr_align(n_inst * 4 * GSR_GROW_FLOATS * 4);
     const size_t flags_bytes = gsr_align(n_inst * 4);
     const size_t sums_bytes = gsr_align(size_t(N > 0 ? N : 1) * GSR_GROW_FLOATS * 4);
-    char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, rows_bytes + flags_bytes + sums_bytes));
+    const bool wide = view->channels != 3;
+    const size_t feat_bytes = wide ? gsr_align(n_inst * 4 * size_t(view->channels) * 4) : 0;   // feature sub-rows
+    char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, rows_bytes + flags_bytes + sums_bytes + feat_bytes));
     if (!scratch) { gsr_set_error("allocator returned NULL (gradient rows)"); return GSR_E_ALLOC; }
+    float* feat_rows = wide ? reinterpret_cast<float*>(scratch + rows_bytes + flags_bytes + sums_bytes) : nullptr;
     float* grad_rows = reinterpret_cast<float*>(scratch);
     uint8_t* row_flags = reinterpret_cast<uint8_t*>(scratch + rows_bytes);
     float* row_sums = reinterpret_cast<float*>(scratch + rows_bytes + flags_bytes);
@@ -275,7 +291,8 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
         GSR_HIP_CHECK(hipMemsetAsync(row_flags, 0, size_t(num_rendered) * 4, s));
         rc = gsr_launch_render_bwd(*view, at<uint32_t>(binning, BL.ranges), at<uint32_t>(binning, BL.inst_row),
                                    at<float>(binning, BL.stream), at<uint8_t>(binning, BL.touch), at<float>(image, IL.final_T),
-                                   at<uint32_t>(image, IL.n_contrib), dL_dcolor, dL_dallmap, grad_rows, row_flags, s);
+                                   at<uint32_t>(image, IL.n_contrib), dL_dcolor, dL_dallmap, grad_rows, row_flags,
+                                   wide ? g->colors_precomp : nullptr, at<uint32_t>(binning, BL.point_list), feat_rows, s);
         if (rc != GSR_OK) return rc;
     }
     GsrGrads o = *grads;
@@ -287,6 +304,16 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     rc = gsr_launch_reduce_rows(N, at<uint32_t>(geom, GL.order), at<uint32_t>(geom, GL.offs), grad_rows,
                                 reinterpret_cast<const uint32_t*>(row_flags), row_sums, s);
     if (rc != GSR_OK) return rc;
+    if (wide) {   // dL_dcolors [N,C] comes from the feature sub-rows, not from the 3 RGB columns of the row sums
+        if (num_rendered > 0) {
+            rc = gsr_launch_reduce_feat_rows(N, view->channels, at<uint32_t>(geom, GL.order), at<uint32_t>(geom, GL.offs),
+                                             feat_rows, reinterpret_cast<const uint32_t*>(row_flags), o.dL_dcolors, s);
+            if (rc != GSR_OK) return rc;
+        } else if (N > 0) {
+            GSR_HIP_CHECK(hipMemsetAsync(o.dL_dcolors, 0, size_t(N) * view->channels * 4, s));
+        }
+        o.dL_dcolors = nullptr;
+    }
     return gsr_launch_preprocess_bwd(*view, *g, radii, at<float>(geom, GL.splat), at<uint32_t>(geom, GL.clamped),
                                      row_sums, o, s);
 }

@@ -129,11 +129,15 @@ int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorte
                              float* stream, hipStream_t s);
 int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* stream,
                           float* final_T, uint32_t* n_contrib, float* out_color,
-                          float* out_allmap, uint8_t* touch, hipStream_t s);
+                          float* out_allmap, uint8_t* touch, const float* feat, const uint32_t* point_list,
+                          hipStream_t s);
 int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* inst_row,
                           const float* stream, const uint8_t* touch, const float* final_T, const uint32_t* n_contrib,
                           const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
-                          uint8_t* row_flags, hipStream_t s);
+                          uint8_t* row_flags, const float* feat, const uint32_t* point_list, float* feat_rows,
+                          hipStream_t s);
+int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint32_t* offs, const float* feat_rows,
+                                const uint32_t* row_flags, float* dL_dcolors, hipStream_t s);
 int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* offs, const float* grad_rows,
                            const uint32_t* row_flags, float* row_sums, hipStream_t s);
 int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int32_t* radii,

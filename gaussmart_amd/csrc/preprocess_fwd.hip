@@ -257,7 +257,7 @@ static void fill_pre_params(PreParams& p, const GsrView& v, const GsrGaussians& 
     p.deg = v.sh_degree; p.M = v.sh_coeffs; p.mod = v.scale_modifier;
     p.view = v.viewmatrix; p.proj = v.projmatrix; p.campos = v.campos;
     p.raw = (v.flags & (uint32_t)GSR_FLAG_RAW_PARAMS) != 0;
-    p.means = g.means3D; p.shs = g.shs; p.shs_rest = g.shs_rest; p.colors = g.colors_precomp; p.opac = g.opacities;
+    p.means = g.means3D; p.shs = g.shs; p.shs_rest = g.shs_rest; p.colors = v.channels == 3 ? g.colors_precomp : nullptr /* wide payloads are read by id in K6/K7 */; p.opac = g.opacities;
     p.scales = g.scales; p.rots = g.rotations; p.tprecomp = g.transmat_precomp;
     p.splat = splat; p.clamped = clamped; p.tiles = tiles_touched; p.dkey = depth_key; p.radii = radii;
 }

@@ -21,6 +21,7 @@
 //     HBM sees plain streaming stores instead of ~18 atomics per pixel-splat pair.
 #include "gsr_common.h"
 #include "pair_eval.h"
+#include "wave_reduce.h"
 
 // five coalesced 16-byte loads per lane = 64 records of 80 bytes; pieces beyond `lim` read as zero
 #define GSR_LOAD5(ptr, lim)                                            \
@@ -46,62 +47,16 @@ struct RenderBwdParams {
     const float* final_T; const uint32_t* n_contrib;
     const float* dL_dcolor; const float* dL_dallmap;
     float* grad_rows; uint8_t* row_flags;
+    // wide payload (FEAT16 > 0): features by Gaussian id, their gradient sub-rows [(instance*4+quad)*C + ch]
+    const float* feat; const uint32_t* point_list; float* feat_rows; int C;
 };
-
-// ---- wave64 reductions -----------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_move(float v) {
-    // lanes whose source is disabled/out of range receive 0 (bound_ctrl)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
-}
-typedef unsigned int gsr_u2 __attribute__((ext_vector_type(2)));
-
-// "Transposed butterfly": sums 16 per-lane values over the 64 lanes in 6 stages while HALVING the
-// number of live registers at each of the first four (gfx950 v_permlane32_swap / v_permlane16_swap,
-// then DPP row_ror:8 and row_half_mirror with a select).  ~50 VALU instead of 16 x 6 DPP steps.
-// On return every lane l holds the wave total of v[l >> 2].
-__device__ __forceinline__ float wave_sum16_transposed(const float (&v)[16], int lane) {
-    float r[8], q[4], p[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {      // bit 5: lanes < 32 keep v[i], lanes >= 32 keep v[i+8]
-        const gsr_u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
-        r[i] = __uint_as_float(t.x) + __uint_as_float(t.y);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {      // bit 4: even rows keep r[i], odd rows keep r[i+4]
-        const gsr_u2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[i]), __float_as_uint(r[i + 4]), false, false);
-        q[i] = __uint_as_float(t.x) + __uint_as_float(t.y);
-    }
-    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {      // bit 3: partner is lane ^ 8 (row_ror:8)
-        const float keep = b3 ? q[i + 2] : q[i], send = b3 ? q[i] : q[i + 2];
-        p[i] = keep + dpp_move<0x128, 0xf>(send);
-    }
-    {                                   // bit 2: partner is lane ^ 7 inside each group of 8 (row_half_mirror)
-        const float keep = b2 ? p[1] : p[0], send = b2 ? p[0] : p[1];
-        p[0] = keep + dpp_move<0x141, 0xf>(send);
-    }
-    p[0] += dpp_move<0xB1, 0xf>(p[0]);  // quad_perm [1,0,3,2]
-    p[0] += dpp_move<0x4E, 0xf>(p[0]);  // quad_perm [2,3,0,1]
-    return p[0];
-}
-// Two values: on return lanes 16..31 hold the wave total of a, lanes 48..63 that of b.
-__device__ __forceinline__ float wave_sum2(float a, float b) {
-    const gsr_u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    float v = __uint_as_float(t.x) + __uint_as_float(t.y);
-    v += dpp_move<0xB1, 0xf>(v);
-    v += dpp_move<0x4E, 0xf>(v);
-    v += dpp_move<0x141, 0xf>(v);   // row_half_mirror
-    v += dpp_move<0x140, 0xf>(v);   // row_mirror: every lane holds its row's sum
-    v += dpp_move<0x142, 0xa>(v);   // row_bcast:15: rows 1 and 3 add the previous row
-    return v;
-}
 
 #ifndef RB_MIN_WAVES
 #define RB_MIN_WAVES 5   // <= 96 VGPRs: measured 1.45 -> 1.35 ms at 1M/1080p
 #endif
-__global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(RenderBwdParams p) {
+// FEAT16: see render_fwd.hip -- 0 = RGB from the record, 1..4 = up to 16*FEAT16 feature channels by id.
+template <int FEAT16>
+__global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) render_bwd_kernel(RenderBwdParams p) {
     __shared__ float4 s_rec_all[RB_WAVES][64 * 5];
 
     const int tid = threadIdx.x;
@@ -138,10 +93,20 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
     const int median_contributor = inside ? (int)p.n_contrib[pix_id + HW] : 0;
 
     float dL_dpix0 = 0.f, dL_dpix1 = 0.f, dL_dpix2 = 0.f;
+    constexpr int NF = FEAT16 > 0 ? 16 * FEAT16 : 1;
+    float dL_dpixf[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) dL_dpixf[k] = 0.f;
     float dL_ddepth = 0.f, dL_daccum = 0.f, dL_dreg = 0.f, dL_dmedian = 0.f;
     float dL_dn0 = 0.f, dL_dn1 = 0.f, dL_dn2 = 0.f;
     if (inside) {
-        dL_dpix0 = p.dL_dcolor[pix_id]; dL_dpix1 = p.dL_dcolor[pix_id + HW]; dL_dpix2 = p.dL_dcolor[pix_id + 2 * HW];
+        if (FEAT16 == 0) {
+            dL_dpix0 = p.dL_dcolor[pix_id]; dL_dpix1 = p.dL_dcolor[pix_id + HW]; dL_dpix2 = p.dL_dcolor[pix_id + 2 * HW];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NF; ++k)
+                if (k < p.C) dL_dpixf[k] = p.dL_dcolor[pix_id + (size_t)k * HW];
+        }
         dL_ddepth = p.dL_dallmap[pix_id + 0 * HW];
         dL_daccum = p.dL_dallmap[pix_id + 1 * HW];
         dL_dn0 = p.dL_dallmap[pix_id + 2 * HW];
@@ -150,7 +115,14 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
         dL_dmedian = p.dL_dallmap[pix_id + 5 * HW];
         dL_dreg = p.dL_dallmap[pix_id + 6 * HW];
     }
-    const float bg_dot_dpixel = p.bg[0] * dL_dpix0 + p.bg[1] * dL_dpix1 + p.bg[2] * dL_dpix2;
+    float bg_dot_dpixel = 0.f;
+    if (FEAT16 == 0) {
+        bg_dot_dpixel = p.bg[0] * dL_dpix0 + p.bg[1] * dL_dpix1 + p.bg[2] * dL_dpix2;
+    } else {
+#pragma unroll
+        for (int k = 0; k < NF; ++k)
+            if (k < p.C) bg_dot_dpixel += p.bg[k] * dL_dpixf[k];
+    }
 
     // running state of the back-to-front recursion
     float T = T_final;
@@ -160,6 +132,7 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
     float4 pf0, pf1, pf2, pf3, pf4;
     uint32_t pf_touch = 0;   // named (not an array): keeps the prefetch in VGPRs, not scratch
     uint32_t pf_row = 0;
+    uint32_t pf_id = 0;
     int hi = max_contrib;
     {
         const int lo = max(0, hi - 64), cnt = hi - lo;
@@ -167,6 +140,7 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
 GSR_LOAD5(src, cnt * 5);
         pf_row = lane < cnt ? p.inst_row[r0 + lo + lane] : 0u;
         pf_touch = lane < cnt ? p.touch[((size_t)r0 + lo + lane) * 4 + wave] : 0u;
+        if (FEAT16 > 0) pf_id = lane < cnt ? p.point_list[r0 + lo + lane] : 0u;
     }
 
     while (hi > 0) {
@@ -174,12 +148,14 @@ GSR_LOAD5(src, cnt * 5);
 s_rec[lane] = pf0; s_rec[64 + lane] = pf1; s_rec[128 + lane] = pf2; s_rec[192 + lane] = pf3; s_rec[256 + lane] = pf4;
         const uint32_t row_of_lane = pf_row;          // emission index of staged entry `lane`
         const uint32_t touch_of_lane = pf_touch;      // did the forward blend staged entry `lane` in this quad?
+        const uint32_t id_of_lane = pf_id;            // Gaussian id of staged entry `lane` (wide payload only)
         {   // prefetch the next (shallower) batch
             const int hi2 = lo, lo2 = max(0, hi2 - 64), cnt = hi2 - lo2;
             const float4* src = p.stream + (size_t)(r0 + lo2) * 5;
 GSR_LOAD5(src, cnt * 5);
             pf_row = lane < cnt ? p.inst_row[r0 + lo2 + lane] : 0u;
             pf_touch = lane < cnt ? p.touch[((size_t)r0 + lo2 + lane) * 4 + wave] : 0u;
+            if (FEAT16 > 0) pf_id = lane < cnt ? p.point_list[r0 + lo2 + lane] : 0u;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -201,6 +177,7 @@ GSR_LOAD5(src, cnt * 5);
             float gT[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float gxy0 = 0.f, gxy1 = 0.f, gn0 = 0.f, gn1 = 0.f, gn2 = 0.f, gopa = 0.f;
             float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f;
+            float w_pair = 0.f;   // blending weight of this pair (wide payload: d feature = w * dL/dpixel)
             if (active) {
                 const float4 a4 = s_rec[j * 5 + 4];
                 const float alpha = pr.alpha, G = pr.G, c_d = pr.depth;
@@ -213,8 +190,24 @@ GSR_LOAD5(src, cnt * 5);
                 //   q_i = c_i . dL/dC + z_i dL/dD + 1 dL/dA + n_i . dL/dN
                 const float c0 = a3.w, c1 = a4.x, c2 = a4.y;
                 const float n0 = a2.w, n1 = a3.x, n2 = a3.y;
-                const float q = c0 * dL_dpix0 + c1 * dL_dpix1 + c2 * dL_dpix2 + c_d * dL_ddepth + dL_daccum
-                              + n0 * dL_dn0 + n1 * dL_dn1 + n2 * dL_dn2;
+                float q = c_d * dL_ddepth + dL_daccum + n0 * dL_dn0 + n1 * dL_dn1 + n2 * dL_dn2;
+                if (FEAT16 == 0) {
+                    q = c0 * dL_dpix0 + c1 * dL_dpix1 + c2 * dL_dpix2 + c_d * dL_ddepth + dL_daccum
+                      + n0 * dL_dn0 + n1 * dL_dn1 + n2 * dL_dn2;
+                } else {
+                    const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id_of_lane, j);   // wave-uniform
+                    const float4* f = reinterpret_cast<const float4*>(p.feat + (size_t)gid * p.C);
+                    float qc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NF / 4; ++k) {
+                        if (4 * k < p.C) {
+                            const float4 v = f[k];
+                            qc += v.x * dL_dpixf[4 * k] + v.y * dL_dpixf[4 * k + 1] + v.z * dL_dpixf[4 * k + 2] + v.w * dL_dpixf[4 * k + 3];
+                        }
+                    }
+                    q += qc;
+                    w_pair = w;
+                }
                 acc_q = last_alpha * last_q + (1.f - last_alpha) * acc_q;
                 last_q = q;
                 float dL_dalpha = q - acc_q;
@@ -276,6 +269,20 @@ GSR_LOAD5(src, cnt * 5);
                 if (lane == 16) row[GSR_GR_XY] = xy;
                 if (lane == 48) row[GSR_GR_XY + 1] = xy;
                 if (lane == 0) p.row_flags[(size_t)e * 4 + wave] = 1;
+                if (FEAT16 > 0) {   // 16 channels per butterfly; lane 4*c ends up holding channel c of the group
+                    float* frow = p.feat_rows + ((size_t)e * 4 + wave) * p.C;
+#pragma unroll
+                    for (int grp = 0; grp < FEAT16; ++grp) {
+                        if (16 * grp < p.C) {
+                            float f16[16];
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) f16[k] = w_pair * dL_dpixf[16 * grp + k];
+                            const float ft = wave_sum16_transposed(f16, lane);
+                            const int ch = 16 * grp + vi;
+                            if ((lane & 3) == 0 && ch < p.C) frow[ch] = ft;
+                        }
+                    }
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();   // all reads of this batch precede the next batch's LDS writes
@@ -283,10 +290,50 @@ GSR_LOAD5(src, cnt * 5);
     }
 }
 
+// Wide payload: add a Gaussian's flagged per-(instance, quad) feature sub-rows in fixed order.  One thread per
+// (depth rank, 4-channel piece); writes dL_dcolors [N,C] by Gaussian id (zeros for Gaussians with no instance).
+__global__ void __launch_bounds__(256) reduce_feat_rows_kernel(long long n_threads, int C4,
+                                                               const uint32_t* __restrict__ order,
+                                                               const uint32_t* __restrict__ offs,
+                                                               const float4* __restrict__ rows,
+                                                               const uint32_t* __restrict__ flags,
+                                                               float4* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_threads) return;
+    const int r = (int)(t / C4), q = (int)(t - (long long)r * C4);
+    const uint32_t e0 = offs[r], e1 = offs[r + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t e = e0; e < e1; ++e) {
+        const uint32_t f = flags[e];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            if ((f >> (8 * sub)) & 0xFFu) {
+                const float4 v = rows[((size_t)e * 4 + sub) * C4 + q];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+    }
+    out[(size_t)order[r] * C4 + q] = acc;
+}
+
+int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint32_t* offs, const float* feat_rows,
+                                const uint32_t* row_flags, float* dL_dcolors, hipStream_t s) {
+    if (N <= 0) return GSR_OK;
+    GsrProfileScope prof(GSR_K_PREPROCESS_BWD, s);
+    const int C4 = C / 4;
+    const long long n_threads = (long long)N * C4;
+    hipLaunchKernelGGL(reduce_feat_rows_kernel, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, s, n_threads, C4,
+                       order, offs, reinterpret_cast<const float4*>(feat_rows), row_flags,
+                       reinterpret_cast<float4*>(dL_dcolors));
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}
+
 int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* inst_row,
                           const float* stream, const uint8_t* touch, const float* final_T, const uint32_t* n_contrib,
                           const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
-                          uint8_t* row_flags, hipStream_t s) {
+                          uint8_t* row_flags, const float* feat, const uint32_t* point_list, float* feat_rows,
+                          hipStream_t s) {
     RenderBwdParams p;
     p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
@@ -294,9 +341,21 @@ int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32
     p.ranges = ranges; p.inst_row = inst_row; p.stream = reinterpret_cast<const float4*>(stream); p.touch = touch; p.bg = v.bg;
     p.final_T = final_T; p.n_contrib = n_contrib; p.dL_dcolor = dL_dcolor; p.dL_dallmap = dL_dallmap;
     p.grad_rows = grad_rows; p.row_flags = row_flags;
+    p.feat = feat; p.point_list = point_list; p.feat_rows = feat_rows; p.C = v.channels;
     if (p.gx <= 0 || gy <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_RENDER_BWD, s);
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(p.gx, gy), dim3(RB_BLOCK), 0, s, p);
+    const dim3 grid(p.gx, gy), block(RB_BLOCK);
+    if (feat == nullptr) {
+        hipLaunchKernelGGL(render_bwd_kernel<0>, grid, block, 0, s, p);
+    } else {
+        switch ((v.channels + 15) / 16) {
+            case 1: hipLaunchKernelGGL(render_bwd_kernel<1>, grid, block, 0, s, p); break;
+            case 2: hipLaunchKernelGGL(render_bwd_kernel<2>, grid, block, 0, s, p); break;
+            case 3: hipLaunchKernelGGL(render_bwd_kernel<3>, grid, block, 0, s, p); break;
+            case 4: hipLaunchKernelGGL(render_bwd_kernel<4>, grid, block, 0, s, p); break;
+            default: gsr_set_error("wide payload supports at most 64 channels"); return GSR_E_UNSUPPORTED;
+        }
+    }
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

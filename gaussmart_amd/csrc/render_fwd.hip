@@ -39,12 +39,18 @@ struct RenderFwdParams {
     const float* bg;
     float* final_T; uint32_t* n_contrib; float* out_color; float* out_allmap;
     uint8_t* touch;
+    // wide payload (FEAT16 > 0): C = 4..64 feature channels per Gaussian instead of the RGB of the record
+    const float* feat; const uint32_t* point_list; int C;
 };
 
 #ifndef RF_MIN_WAVES
 #define RF_MIN_WAVES 8   // <= 64 VGPRs: measured 0.645 -> 0.59 ms at 1M/1080p
 #endif
-__global__ void __launch_bounds__(RF_BLOCK, RF_MIN_WAVES) render_fwd_kernel(RenderFwdParams p) {
+// FEAT16 = 0: three colour channels taken from the splat record (the reference's configuration).
+// FEAT16 = 1..4: up to 16*FEAT16 feature channels read from `feat` [N,C] by Gaussian id with wave-uniform
+// 16-byte loads (wide per-pixel payload); everything else is identical.
+template <int FEAT16>
+__global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : 2) render_fwd_kernel(RenderFwdParams p) {
     __shared__ float4 s_rec_all[RF_WAVES][64 * 5];
 
     const int tid = threadIdx.x;
@@ -67,6 +73,11 @@ __global__ void __launch_bounds__(RF_BLOCK, RF_MIN_WAVES) render_fwd_kernel(Rend
     float T = 1.0f;
     uint32_t last_contributor = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    constexpr int NF = FEAT16 > 0 ? 16 * FEAT16 : 1;
+    float Cf[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) Cf[k] = 0.f;
+    uint32_t pf_id = 0;
     float N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float Dacc = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med_depth = 0.f;
     uint32_t med_contrib = 0xFFFFFFFFu;   // "-1" stored in the u32 plane, as recalled
@@ -78,17 +89,20 @@ __global__ void __launch_bounds__(RF_BLOCK, RF_MIN_WAVES) render_fwd_kernel(Rend
     {
         const int lim = min(64, n_list) * 5;
 GSR_LOAD5(src, lim);
+        if (FEAT16 > 0 && lane < min(64, n_list)) pf_id = p.point_list[r0 + lane];
     }
 
     for (int base = 0; base < n_list; base += 64) {
         if (__all(done)) break;
         const int nb = min(64, n_list - base);
 s_rec[lane] = pf0; s_rec[64 + lane] = pf1; s_rec[128 + lane] = pf2; s_rec[192 + lane] = pf3; s_rec[256 + lane] = pf4;
+        const uint32_t id_of_lane = pf_id;
         {   // prefetch the next batch while this one is composited
             const int nxt = base + 64;
             const int lim = nxt < n_list ? min(64, n_list - nxt) * 5 : 0;
             const float4* s2 = src + (size_t)nxt * 5;
 GSR_LOAD5(s2, lim);
+            if (FEAT16 > 0 && nxt < n_list && lane < min(64, n_list - nxt)) pf_id = p.point_list[r0 + nxt + lane];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -125,7 +139,19 @@ GSR_LOAD5(s2, lim);
             M2 += m_d * m_d * w;
             if (T > 0.5f) { med_depth = depth; med_contrib = contributor; }
             N0 += a2.w * w; N1 += a3.x * w; N2 += a3.y * w;
-            C0 += a3.w * w; C1 += a4.x * w; C2 += a4.y * w;
+            if (FEAT16 == 0) {
+                C0 += a3.w * w; C1 += a4.x * w; C2 += a4.y * w;
+            } else {
+                const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id_of_lane, j);   // wave-uniform
+                const float4* f = reinterpret_cast<const float4*>(p.feat + (size_t)gid * p.C);
+#pragma unroll
+                for (int k = 0; k < NF / 4; ++k) {
+                    if (4 * k < p.C) {
+                        const float4 v = f[k];
+                        Cf[4 * k] += v.x * w; Cf[4 * k + 1] += v.y * w; Cf[4 * k + 2] += v.z * w; Cf[4 * k + 3] += v.w * w;
+                    }
+                }
+            }
             T = test_T;
             last_contributor = contributor;
             const unsigned long long bit = 1ull << j;          // wave-uniform (scalar shift)
@@ -151,9 +177,15 @@ GSR_LOAD5(s2, lim);
         p.final_T[pix_id + 2 * HW] = M2;
         p.n_contrib[pix_id] = last_contributor;
         p.n_contrib[pix_id + HW] = med_contrib;
-        p.out_color[pix_id] = C0 + T * p.bg[0];
-        p.out_color[pix_id + HW] = C1 + T * p.bg[1];
-        p.out_color[pix_id + 2 * HW] = C2 + T * p.bg[2];
+        if (FEAT16 == 0) {
+            p.out_color[pix_id] = C0 + T * p.bg[0];
+            p.out_color[pix_id + HW] = C1 + T * p.bg[1];
+            p.out_color[pix_id + 2 * HW] = C2 + T * p.bg[2];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NF; ++k)
+                if (k < p.C) p.out_color[pix_id + (size_t)k * HW] = Cf[k] + T * p.bg[k];
+        }
         p.out_allmap[pix_id + 0 * HW] = Dacc;
         p.out_allmap[pix_id + 1 * HW] = 1.0f - T;
         p.out_allmap[pix_id + 2 * HW] = N0;
@@ -166,16 +198,28 @@ GSR_LOAD5(s2, lim);
 
 int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* stream,
                           float* final_T, uint32_t* n_contrib, float* out_color,
-                          float* out_allmap, uint8_t* touch, hipStream_t s) {
+                          float* out_allmap, uint8_t* touch, const float* feat, const uint32_t* point_list,
+                          hipStream_t s) {
     RenderFwdParams p;
     p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE; p.flags = v.flags;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
     p.ranges = ranges; p.stream = reinterpret_cast<const float4*>(stream); p.bg = v.bg;
     p.final_T = final_T; p.n_contrib = n_contrib; p.out_color = out_color; p.out_allmap = out_allmap;
-    p.touch = touch;
+    p.touch = touch; p.feat = feat; p.point_list = point_list; p.C = v.channels;
     if (p.gx <= 0 || gy <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_RENDER_FWD, s);
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(p.gx, gy), dim3(RF_BLOCK), 0, s, p);
+    const dim3 grid(p.gx, gy), block(RF_BLOCK);
+    if (feat == nullptr) {
+        hipLaunchKernelGGL(render_fwd_kernel<0>, grid, block, 0, s, p);
+    } else {
+        switch ((v.channels + 15) / 16) {
+            case 1: hipLaunchKernelGGL(render_fwd_kernel<1>, grid, block, 0, s, p); break;
+            case 2: hipLaunchKernelGGL(render_fwd_kernel<2>, grid, block, 0, s, p); break;
+            case 3: hipLaunchKernelGGL(render_fwd_kernel<3>, grid, block, 0, s, p); break;
+            case 4: hipLaunchKernelGGL(render_fwd_kernel<4>, grid, block, 0, s, p); break;
+            default: gsr_set_error("wide payload supports at most 64 channels"); return GSR_E_UNSUPPORTED;
+        }
+    }
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

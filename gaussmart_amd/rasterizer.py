@@ -182,15 +182,16 @@ def release_workspace():
     _POOL.clear()
 
 
-def _make_view(rs: GaussianRasterizationSettings, sh_coeffs: int, flags: int, device):
+def _make_view(rs: GaussianRasterizationSettings, sh_coeffs: int, flags: int, device, channels: int = 3):
     bg = _f32c(rs.bg, "bg", device)
     vm = _f32c(rs.viewmatrix, "viewmatrix", device)
     pm = _f32c(rs.projmatrix, "projmatrix", device)
     cp = _f32c(rs.campos, "campos", device)
-    if bg.numel() != 3 or vm.numel() != 16 or pm.numel() != 16 or cp.numel() != 3:
-        raise ValueError("bg/campos must have 3 elements, viewmatrix/projmatrix 16")
+    if bg.numel() != channels or vm.numel() != 16 or pm.numel() != 16 or cp.numel() != 3:
+        raise ValueError(f"bg must have {channels} elements (one per output channel), campos 3, "
+                         "viewmatrix/projmatrix 16")
     v = _lib.GsrView(int(rs.image_width), int(rs.image_height), float(rs.tanfovx), float(rs.tanfovy),
-                     float(rs.scale_modifier), int(rs.sh_degree), int(sh_coeffs), 3, int(flags),
+                     float(rs.scale_modifier), int(rs.sh_degree), int(sh_coeffs), int(channels), int(flags),
                      bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr())
     return v, (bg, vm, pm, cp)
 
@@ -214,15 +215,19 @@ class _RasterizeGaussians(torch.autograd.Function):
         scales = _f32c(scales, "scales", device)
         rotations = _f32c(rotations, "rotations", device)
         cov3Ds_precomp = _f32c(cov3Ds_precomp, "cov3D_precomp", device)
-        if colors_precomp is not None and (colors_precomp.dim() != 2 or colors_precomp.shape[1] != 3):
-            raise _lib.GsrError("colors_precomp must be [N,3] (N-channel payloads are not supported yet)")
+        channels = 3
+        if colors_precomp is not None:
+            # [N,3] RGB, or a wide per-pixel payload [N,C] with C = 4, 8, ... 64 (semantic / feature splatting)
+            if colors_precomp.dim() != 2 or colors_precomp.shape[0] != N:
+                raise _lib.GsrError("colors_precomp must be [N,C]")
+            channels = int(colors_precomp.shape[1])
         sh_coeffs = sh.shape[1] if sh is not None else 0
 
         with torch.cuda.device(device):
-            view, keep = _make_view(rs, sh_coeffs, flags, device)
+            view, keep = _make_view(rs, sh_coeffs, flags, device, channels)
             g = _lib.GsrGaussians(N, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities),
                                   _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp), None)
-            color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+            color = torch.empty((channels, H, W), dtype=torch.float32, device=device)
             allmap = torch.empty((7, H, W), dtype=torch.float32, device=device)
             radii = torch.empty((N,), dtype=torch.int32, device=device)
             out = _lib.GsrForwardOut(color.data_ptr(), allmap.data_ptr(), radii.data_ptr(), 0, None, None, None)
@@ -235,6 +240,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.check(rc)
 
         ctx.lease = alloc.kept          # geom / binning / image go back to the pool with this node
+        ctx.channels = channels
         ctx.raster_settings = rs
         ctx.flags = flags
         ctx.num_rendered = int(out.num_rendered)
@@ -270,12 +276,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         N = means3D.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
         grad_color = _f32c(grad_color, "grad_color", device) if grad_color is not None else \
-            torch.zeros((3, H, W), device=device)
+            torch.zeros((ctx.channels, H, W), device=device)
         grad_allmap = _f32c(grad_allmap, "grad_allmap", device) if grad_allmap is not None else \
             torch.zeros((7, H, W), device=device)
 
         with torch.cuda.device(device):
-            view, keep = _make_view(rs, sh.shape[1] if sh is not None else 0, ctx.flags, device)
+            view, keep = _make_view(rs, sh.shape[1] if sh is not None else 0, ctx.flags, device, ctx.channels)
             g = _lib.GsrGaussians(N, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities),
                                   _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp), None)
             d_means3D = torch.empty_like(means3D)

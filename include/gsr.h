@@ -32,6 +32,7 @@ extern "C" {
 #endif
 
 #define GSR_ABI_VERSION 2
+#define GSR_MAX_CHANNELS 64   /* widest per-pixel payload of gsr_forward / gsr_backward */
 
 typedef void* gsr_stream_t; /* hipStream_t */
 
@@ -40,7 +41,7 @@ enum {
     GSR_E_INVALID = -1,     /* bad argument combination (mirrors the operator's Python checks) */
     GSR_E_HIP = -2,         /* a HIP runtime call failed                                        */
     GSR_E_ALLOC = -3,       /* the caller's allocator returned NULL                             */
-    GSR_E_UNSUPPORTED = -4  /* e.g. channels != 3, sh_degree > 3                                */
+    GSR_E_UNSUPPORTED = -4  /* e.g. channels not in {3, 4..64 step 4}, sh_degree > 3            */
 };
 
 /* GsrView.flags: reproduce the two places where the recalled upstream backward is not the
@@ -63,7 +64,8 @@ typedef struct GsrView {
     float scale_modifier;
     int32_t sh_degree;       /* active degree, 0..3                                  */
     int32_t sh_coeffs;       /* coefficients stored per Gaussian (shs is [N, M, 3])  */
-    int32_t channels;        /* colour channels, must be 3                           */
+    int32_t channels;        /* 3 (RGB), or 4..GSR_MAX_CHANNELS (multiple of 4) with
+                                colors_precomp [N,channels]: wide per-pixel payload  */
     uint32_t flags;          /* GSR_FLAG_*                                           */
     const float* bg;         /* device f32[channels]                                 */
     const float* viewmatrix; /* device f32[16]                                       */
@@ -77,7 +79,7 @@ typedef struct GsrGaussians {
     int32_t count;                 /* N                                              */
     const float* means3D;          /* device [N,3]                                   */
     const float* shs;              /* device [N,M,3] or NULL                         */
-    const float* colors_precomp;   /* device [N,3] or NULL                           */
+    const float* colors_precomp;   /* device [N,channels] or NULL (16-byte aligned when channels != 3) */
     const float* opacities;        /* device [N] (post-sigmoid)                      */
     const float* scales;           /* device [N,2] (post-exp) or NULL                */
     const float* rotations;        /* device [N,4] (w,x,y,z) or NULL                 */
@@ -114,7 +116,7 @@ typedef struct GsrGrads {
                              (consumer scene/gaussian_model.py:551-553)                */
     float* dL_dopacity;   /* device [N]                                                */
     float* dL_dshs;       /* device [N,M,3] or NULL                                    */
-    float* dL_dcolors;    /* device [N,3] or NULL (when colors_precomp was given)      */
+    float* dL_dcolors;    /* device [N,channels] or NULL (when colors_precomp was given) */
     float* dL_dscales;    /* device [N,2] or NULL                                      */
     float* dL_drotations; /* device [N,4] or NULL                                      */
     float* dL_dtransmat;  /* device [N,9] or NULL (when transmat_precomp was given)    */

@@ -147,7 +147,8 @@ def _grad_compare(a, cam, dev, flags, bg=(0.2, 0.4, 0.6), colors=None, cov=None,
     N = a["means3D"].shape[0]
     W, H = cam.image_width, cam.image_height
     g = torch.Generator().manual_seed(seed)
-    wc, wa = torch.randn(3, H, W, generator=g), torch.randn(7, H, W, generator=g)
+    n_ch = a["colors_precomp"].shape[1] if a.get("colors_precomp") is not None else 3
+    wc, wa = torch.randn(n_ch, H, W, generator=g), torch.randn(7, H, W, generator=g)
     names = [k for k in ("means3D", "opacities", "shs", "scales", "rotations", "colors_precomp", "cov3D_precomp") if a.get(k) is not None]
     hin = {k: a[k].clone().to(dev).requires_grad_(True) for k in names}
     m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
