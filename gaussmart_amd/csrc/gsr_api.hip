@@ -273,27 +273,41 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     const GsrBinLayout BL(num_rendered, gx * gy);
     const GsrImageLayout IL((int64_t)W * H);
 
-    // 4 sub-rows (one per quad) of 80 bytes per instance + one flag byte per sub-row + per-Gaussian sums
+    // Gradient rows: one 80-byte row per (instance, 4x4 pixel block the forward blended it into), DENSE in
+    // (emission index, quad, block) order.  Their number R <= 16 D is only known on the device (scan below), so
+    // the buffer is sized for the bound; only its first R rows are ever touched.
     const size_t n_inst = size_t(num_rendered > 0 ? num_rendered : 1);
-    const size_t rows_bytes = gsr_align(n_inst * 4 * GSR_GROW_FLOATS * 4);
-    const size_t flags_bytes = gsr_align(n_inst * 4);
+    const size_t rows_bytes = gsr_align(n_inst * GSR_SUBROWS * GSR_GROW_FLOATS * 4);
+    const size_t cnt_bytes = gsr_align(n_inst * 4);
+    const size_t slot_bytes = gsr_align((n_inst + 1) * 4);
+    const size_t scan_bytes = gsr_scan_workspace_bytes((int64_t)n_inst);
     const size_t sums_bytes = gsr_align(size_t(N > 0 ? N : 1) * GSR_GROW_FLOATS * 4);
     const bool wide = view->channels != 3;
-    const size_t feat_bytes = wide ? gsr_align(n_inst * 4 * size_t(view->channels) * 4) : 0;   // feature sub-rows
-    char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, rows_bytes + flags_bytes + sums_bytes + feat_bytes));
+    const size_t feat_bytes = wide ? gsr_align(n_inst * GSR_SUBROWS * size_t(view->channels) * 4) : 0;   // feature rows
+    char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH,
+                                             rows_bytes + cnt_bytes + slot_bytes + scan_bytes + sums_bytes + feat_bytes));
     if (!scratch) { gsr_set_error("allocator returned NULL (gradient rows)"); return GSR_E_ALLOC; }
-    float* feat_rows = wide ? reinterpret_cast<float*>(scratch + rows_bytes + flags_bytes + sums_bytes) : nullptr;
     float* grad_rows = reinterpret_cast<float*>(scratch);
-    uint8_t* row_flags = reinterpret_cast<uint8_t*>(scratch + rows_bytes);
-    float* row_sums = reinterpret_cast<float*>(scratch + rows_bytes + flags_bytes);
+    uint32_t* slot_cnt = reinterpret_cast<uint32_t*>(scratch + rows_bytes);
+    uint32_t* slot_off = reinterpret_cast<uint32_t*>(scratch + rows_bytes + cnt_bytes);
+    void* scan_ws = scratch + rows_bytes + cnt_bytes + slot_bytes;
+    float* row_sums = reinterpret_cast<float*>(scratch + rows_bytes + cnt_bytes + slot_bytes + scan_bytes);
+    float* feat_rows = wide ? reinterpret_cast<float*>(scratch + rows_bytes + cnt_bytes + slot_bytes + scan_bytes + sums_bytes)
+                            : nullptr;
 
     if (num_rendered > 0) {
-        GSR_HIP_CHECK(hipMemsetAsync(row_flags, 0, size_t(num_rendered) * 4, s));
+        const uint32_t* touch = at<uint32_t>(binning, BL.touch);
+        rc = gsr_launch_slot_count(num_rendered, touch, at<uint32_t>(binning, BL.inst_row), slot_cnt, s);
+        if (rc != GSR_OK) return rc;
+        rc = gsr_exclusive_scan_u32(slot_cnt, nullptr, slot_off, num_rendered, scan_ws, s);
+        if (rc != GSR_OK) return rc;
         rc = gsr_launch_render_bwd(*view, at<uint32_t>(binning, BL.ranges), at<uint32_t>(binning, BL.inst_row),
-                                   at<float>(binning, BL.stream), at<uint8_t>(binning, BL.touch), at<float>(image, IL.final_T),
-                                   at<uint32_t>(image, IL.n_contrib), dL_dcolor, dL_dallmap, grad_rows, row_flags,
+                                   at<float>(binning, BL.stream), touch, slot_off, at<float>(image, IL.final_T),
+                                   at<uint32_t>(image, IL.n_contrib), dL_dcolor, dL_dallmap, grad_rows,
                                    wide ? g->colors_precomp : nullptr, at<uint32_t>(binning, BL.point_list), feat_rows, s);
         if (rc != GSR_OK) return rc;
+    } else {
+        GSR_HIP_CHECK(hipMemsetAsync(slot_off, 0, 8, s));
     }
     GsrGrads o = *grads;
     if (!g->shs) o.dL_dshs = nullptr;
@@ -301,13 +315,13 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     if (!g->colors_precomp) o.dL_dcolors = nullptr;
     if (!g->scales) { o.dL_dscales = nullptr; o.dL_drotations = nullptr; }
     if (!g->transmat_precomp) o.dL_dtransmat = nullptr;
-    rc = gsr_launch_reduce_rows(N, at<uint32_t>(geom, GL.order), at<uint32_t>(geom, GL.offs), grad_rows,
-                                reinterpret_cast<const uint32_t*>(row_flags), row_sums, s);
+    rc = gsr_launch_reduce_rows(N, at<uint32_t>(geom, GL.order), at<uint32_t>(geom, GL.offs), slot_off, grad_rows,
+                                row_sums, s);
     if (rc != GSR_OK) return rc;
     if (wide) {   // dL_dcolors [N,C] comes from the feature sub-rows, not from the 3 RGB columns of the row sums
         if (num_rendered > 0) {
             rc = gsr_launch_reduce_feat_rows(N, view->channels, at<uint32_t>(geom, GL.order), at<uint32_t>(geom, GL.offs),
-                                             feat_rows, reinterpret_cast<const uint32_t*>(row_flags), o.dL_dcolors, s);
+                                             slot_off, feat_rows, o.dL_dcolors, s);
             if (rc != GSR_OK) return rc;
         } else if (N > 0) {
             GSR_HIP_CHECK(hipMemsetAsync(o.dL_dcolors, 0, size_t(N) * view->channels * 4, s));

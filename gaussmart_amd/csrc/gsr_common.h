@@ -54,6 +54,7 @@ struct GsrProfileScope {
 // summed by preprocess_bwd; a byte flag per sub-row says whether it was written at all:
 // [dTu.xyz dTv.xyz dTw.xyz | dxy | dn.xyz | dopa | drgb | pad pad]
 #define GSR_GROW_FLOATS 20
+#define GSR_SUBROWS 16        // gradient sub-rows per instance: one per 4x4 pixel block of the 16x16 tile
 #define GSR_GR_T 0
 #define GSR_GR_XY 9
 #define GSR_GR_NRM 11
@@ -131,15 +132,15 @@ int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float*
                           float* final_T, uint32_t* n_contrib, float* out_color,
                           float* out_allmap, uint8_t* touch, const float* feat, const uint32_t* point_list,
                           hipStream_t s);
+int gsr_launch_slot_count(int D, const uint32_t* touch, const uint32_t* inst_row, uint32_t* cnt, hipStream_t s);
 int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* inst_row,
-                          const float* stream, const uint8_t* touch, const float* final_T, const uint32_t* n_contrib,
-                          const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
-                          uint8_t* row_flags, const float* feat, const uint32_t* point_list, float* feat_rows,
-                          hipStream_t s);
-int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint32_t* offs, const float* feat_rows,
-                                const uint32_t* row_flags, float* dL_dcolors, hipStream_t s);
-int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* offs, const float* grad_rows,
-                           const uint32_t* row_flags, float* row_sums, hipStream_t s);
+                          const float* stream, const uint32_t* touch, const uint32_t* slot_off, const float* final_T,
+                          const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
+                          const float* feat, const uint32_t* point_list, float* feat_rows, hipStream_t s);
+int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint32_t* offs, const uint32_t* slot_off,
+                                const float* feat_rows, float* dL_dcolors, hipStream_t s);
+int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* offs, const uint32_t* slot_off,
+                           const float* grad_rows, float* row_sums, hipStream_t s);
 int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int32_t* radii,
                               const float* splat, const uint32_t* clamped, const float* row_sums,
                               const GsrGrads& out, hipStream_t s);

@@ -1,7 +1,7 @@
 // K8 preprocess_bwd, two launches:
-//   reduce_rows : 5 threads per Gaussian IN DEPTH-RANK ORDER (so the instance rows are swept almost
-//      sequentially) add its flagged per-(instance, quad) gradient sub-rows in a fixed order, one
-//      16-byte piece per thread, and scatter the 80-byte sum to the Gaussian's id;
+//   reduce_rows : 16 lanes per Gaussian IN DEPTH-RANK ORDER add its per-(instance, 4x4 block) gradient
+//      rows -- one contiguous run of 80-byte rows -- in a fixed order and scatter the 80-byte sum to the
+//      Gaussian's id;
 //   preprocess_bwd : one thread per Gaussian, id order:
 //   1. read its 80-byte row sum,
 //   2. densification statistic for means2D.grad (consumer scene/gaussian_model.py:551-553),
@@ -12,6 +12,7 @@
 // block is staged through LDS both ways so global traffic is coalesced 16-byte accesses.
 #include "gsr_common.h"
 #include "sh_stage.h"
+#include "wave_reduce.h"
 
 #define PB_BLOCK 256
 
@@ -28,36 +29,53 @@ struct PreBwdParams {
     GsrGrads out;
 };
 
-__global__ void __launch_bounds__(256) reduce_rows_kernel(long long n_threads, const uint32_t* __restrict__ order,
+// 16 lanes (one DPP row) per Gaussian, in depth-rank order.  Instance e owns the dense gradient rows
+// [slot_off[e], slot_off[e + 1]) and a Gaussian's instances are consecutive in emission order, so ALL rows of
+// a Gaussian are one contiguous run of 80-byte rows.  Lanes 0..14 read it three rows (240 contiguous bytes) per
+// round, four rounds in flight: lane s always handles 16-byte column group s % 5 of row 3k + s / 5.  Two DPP
+// shifts then add the three lanes that share a column group.  Fixed order => bitwise reproducible gradients.
+__global__ void __launch_bounds__(256) reduce_rows_kernel(int N, const uint32_t* __restrict__ order,
                                                           const uint32_t* __restrict__ offs,
+                                                          const uint32_t* __restrict__ slot_off,
                                                           const float4* __restrict__ rows,
-                                                          const uint32_t* __restrict__ flags,
                                                           float4* __restrict__ sums) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_threads) return;
-    const int r = (int)(t / 5), q = (int)(t - (long long)r * 5);
-    const uint32_t e0 = offs[r], e1 = offs[r + 1];
+    const int r = (int)(t >> 4), s16 = (int)(t & 15);
+    const bool valid = r < N && s16 < 15;
+    uint32_t s0 = 0, s1 = 0;
+    if (valid) { s0 = slot_off[offs[r]]; s1 = slot_off[offs[r + 1]]; }
+    const int n_rows = (int)(s1 - s0);
+    const int sub0 = s16 / 5;                       // 0..2: row inside the round
+    const float4* src = rows + (size_t)s0 * 5 + s16;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t e = e0; e < e1; ++e) {
-        const uint32_t f = flags[e];                 // four byte flags: which quads wrote a sub-row
+    for (int k0 = 0; 3 * k0 < n_rows; k0 += 4) {
+        float4 v[4];
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            if ((f >> (8 * sub)) & 0xFFu) {
-                const float4 v = rows[((size_t)e * 4 + sub) * 5 + q];
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
+        for (int u = 0; u < 4; ++u) {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (3 * (k0 + u) + sub0 < n_rows) v[u] = src[15 * (k0 + u)];
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
-    sums[(size_t)order[r] * 5 + q] = acc;
+    // all 64 lanes reach this point.  Lanes s, s + 5, s + 10 hold the same column group.
+    float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float a5 = dpp_move<0x115, 0xf>(o[c]);    // row_shr:5  (lane s receives lane s - 5)
+        const float a10 = dpp_move<0x11A, 0xf>(o[c]);   // row_shr:10
+        o[c] = (o[c] + a5) + a10;
+    }
+    if (valid && s16 >= 10) sums[(size_t)order[r] * 5 + (s16 - 10)] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* offs, const float* grad_rows,
-                           const uint32_t* row_flags, float* row_sums, hipStream_t s) {
+int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* offs, const uint32_t* slot_off,
+                           const float* grad_rows, float* row_sums, hipStream_t s) {
     if (N <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_PREPROCESS_BWD, s);
-    const long long n_threads = (long long)N * 5;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, s, n_threads, order, offs,
-                       reinterpret_cast<const float4*>(grad_rows), row_flags, reinterpret_cast<float4*>(row_sums));
+    const long long n_threads = (long long)N * 16;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, s, N, order, offs,
+                       slot_off, reinterpret_cast<const float4*>(grad_rows), reinterpret_cast<float4*>(row_sums));
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

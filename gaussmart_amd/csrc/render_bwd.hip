@@ -4,20 +4,22 @@
 // median depth, distortion), see DESIGN.md section "render_bwd" for the recursion; it is the exact
 // derivative of render_fwd except for the two flagged quirks (GSR_FLAG_*).
 //
-// MI355X mapping: WAVE-INDEPENDENT, like the forward.  Each wave64 of a tile's workgroup owns an 8x8
-// pixel quad and never synchronises with the other three:
-//   * it starts at the deepest list entry ANY OF ITS 64 PIXELS reached (quad-level, not tile-level)
+// MI355X mapping: WAVE-INDEPENDENT, like the forward, and BLOCK-INDEPENDENT inside the wave.  Each wave64 of
+// a tile's workgroup owns an 8x8 pixel quad and never synchronises with the other three; each DPP row of
+// 16 lanes owns one 4x4 pixel block of that quad and walks ITS OWN list:
+//   * the wave starts at the deepest list entry ANY OF ITS 64 PIXELS reached (quad-level, not tile-level)
 //     and streams the (tile, depth)-ordered splat records backwards, 64 per batch, coalesced, into
 //     its private LDS slice while the next batch is prefetched into registers;
-//   * a 64-bit ballot of the forward's "blended into >= 1 pixel of this quad" bytes selects EXACTLY
-//     the splats that carry gradient here; nothing else is even evaluated;
+//   * the forward left 4 bits per (instance, quad): "blended into >= 1 pixel of block g".  Four ballots
+//     turn them into one 64-bit to-do mask PER BLOCK; every iteration each row takes the deepest entry
+//     of its own mask, so the wave needs max_g |list_g| iterations instead of |union of the lists|
+//     (measured at 1M/1080p: 0.67x the iterations; lane utilisation 30 % -> 45 %);
 //   * the suffix recursions of colour, depth, alpha and normal are collapsed into ONE scalar
 //     recursion (they are linear: q_i = c_i.dL/dC + z_i dL/dD + dL/dA + n_i.dL/dN);
-//   * the 18 partial derivatives are summed over the 64 pixels with the transposed butterfly below
-//     (gfx950 v_permlane32_swap / v_permlane16_swap + DPP, ~50 VALU) and land distributed over the
-//     lanes, which store them straight into the wave's OWN 80-byte sub-row of that instance
-//     (4 sub-rows per instance, one per quad) plus a 1-byte "written" flag;
-//   * preprocess_bwd adds the flagged sub-rows in fixed order => bitwise reproducible gradients, and
+//   * the 18 partial derivatives are summed over the 16 pixels of the block with the transposed butterfly
+//     of wave_reduce.h (DPP only, ~50 VALU) and land one per lane, which store them straight into the
+//     block's OWN 80-byte sub-row of that instance (16 sub-rows per instance) plus a 1-byte flag;
+//   * reduce_rows adds the flagged sub-rows in fixed order => bitwise reproducible gradients, and
 //     HBM sees plain streaming stores instead of ~18 atomics per pixel-splat pair.
 #include "gsr_common.h"
 #include "pair_eval.h"
@@ -43,16 +45,16 @@ struct RenderBwdParams {
     int W, H, gx;
     uint32_t flags;
     const uint32_t* ranges; const uint32_t* inst_row;
-    const float4* stream; const uint8_t* touch; const float* bg;
+    const float4* stream; const uint32_t* touch; const uint32_t* slot_off; const float* bg;
     const float* final_T; const uint32_t* n_contrib;
     const float* dL_dcolor; const float* dL_dallmap;
-    float* grad_rows; uint8_t* row_flags;
+    float* grad_rows;
     // wide payload (FEAT16 > 0): features by Gaussian id, their gradient sub-rows [(instance*4+quad)*C + ch]
     const float* feat; const uint32_t* point_list; float* feat_rows; int C;
 };
 
 #ifndef RB_MIN_WAVES
-#define RB_MIN_WAVES 5   // <= 96 VGPRs: measured 1.45 -> 1.35 ms at 1M/1080p
+#define RB_MIN_WAVES 4   // <= 128 VGPRs, no scratch: measured 0.825 ms at 1M/1080p (5 waves spill: 1.13 ms)
 #endif
 // FEAT16: see render_fwd.hip -- 0 = RGB from the record, 1..4 = up to 16*FEAT16 feature channels by id.
 template <int FEAT16>
@@ -64,7 +66,9 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
     float4* s_rec = s_rec_all[wave];
     const int tile_x = blockIdx.x, tile_y = blockIdx.y;
     const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
-    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const int grp = lane >> 4, l16 = lane & 15;   // DPP row = 4x4 pixel block, same mapping as render_fwd
+    const uint32_t below_mask = ((1u << (8 * wave + grp)) - 1u) & 0x0F0F0F0Fu;   // touch bits of the blocks before mine
+    const int pxi = qx0 + (grp & 1) * 4 + (l16 & 3), pyi = qy0 + (grp >> 1) * 4 + (l16 >> 2);
     const bool inside = pxi < p.W && pyi < p.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
     const int pix_id = pyi * p.W + pxi;
@@ -83,7 +87,6 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
 
     const bool clamp_pass = (p.flags & GSR_FLAG_CLAMP_PASSTHROUGH) != 0;
     const bool filter_depth_quirk = (p.flags & GSR_FLAG_FILTER_DEPTH_GRAD) != 0;
-    const bool no_cull = (p.flags & (uint32_t)GSR_FLAG_DEBUG_NO_CULL) != 0;
 
     // per-pixel state saved by the forward
     const float T_final = inside ? p.final_T[pix_id] : 0.f;
@@ -139,7 +142,7 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
         const float4* src = p.stream + (size_t)(r0 + lo) * 5;
 GSR_LOAD5(src, cnt * 5);
         pf_row = lane < cnt ? p.inst_row[r0 + lo + lane] : 0u;
-        pf_touch = lane < cnt ? p.touch[((size_t)r0 + lo + lane) * 4 + wave] : 0u;
+        pf_touch = lane < cnt ? p.touch[(size_t)r0 + lo + lane] : 0u;
         if (FEAT16 > 0) pf_id = lane < cnt ? p.point_list[r0 + lo + lane] : 0u;
     }
 
@@ -147,37 +150,55 @@ GSR_LOAD5(src, cnt * 5);
         const int lo = max(0, hi - 64), nb = hi - lo;
 s_rec[lane] = pf0; s_rec[64 + lane] = pf1; s_rec[128 + lane] = pf2; s_rec[192 + lane] = pf3; s_rec[256 + lane] = pf4;
         const uint32_t row_of_lane = pf_row;          // emission index of staged entry `lane`
-        const uint32_t touch_of_lane = pf_touch;      // did the forward blend staged entry `lane` in this quad?
+        const uint32_t touch_of_lane = pf_touch;      // 4 bytes (one per quad) x 4 bits (one per 4x4 block): blended there?
+        // first gradient row of staged entry `lane` (its rows are dense, in (quad, block) order of the set bits)
+        const uint32_t slot_of_lane = lane < nb ? p.slot_off[row_of_lane] : 0u;
         const uint32_t id_of_lane = pf_id;            // Gaussian id of staged entry `lane` (wide payload only)
         {   // prefetch the next (shallower) batch
             const int hi2 = lo, lo2 = max(0, hi2 - 64), cnt = hi2 - lo2;
             const float4* src = p.stream + (size_t)(r0 + lo2) * 5;
 GSR_LOAD5(src, cnt * 5);
             pf_row = lane < cnt ? p.inst_row[r0 + lo2 + lane] : 0u;
-            pf_touch = lane < cnt ? p.touch[((size_t)r0 + lo2 + lane) * 4 + wave] : 0u;
+            pf_touch = lane < cnt ? p.touch[(size_t)r0 + lo2 + lane] : 0u;
             if (FEAT16 > 0) pf_id = lane < cnt ? p.point_list[r0 + lo2 + lane] : 0u;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        // only the splats the forward blended into >= 1 pixel of this quad carry any gradient
-        const bool ov = lane < nb && (no_cull || touch_of_lane != 0u);
-        unsigned long long todo_mask = __ballot(ov);
-        while (todo_mask) {
-            const int j = 63 - __builtin_clzll(todo_mask);      // deepest first
-            todo_mask &= ~(1ull << j);
+        // only the splats the forward blended into >= 1 pixel of a block carry any gradient there: one to-do
+        // mask per 4x4 block (= DPP row), held by all 16 lanes of the row
+        uint32_t todo_lo, todo_hi;
+        {
+            const uint32_t t = lane < nb ? (touch_of_lane >> (8 * wave)) & 0xFu : 0u;
+            const unsigned long long m0 = __ballot((t & 1u) != 0), m1 = __ballot((t & 2u) != 0);
+            const unsigned long long m2 = __ballot((t & 4u) != 0), m3 = __ballot((t & 8u) != 0);
+            const unsigned long long mm = grp == 0 ? m0 : grp == 1 ? m1 : grp == 2 ? m2 : m3;
+            todo_lo = (uint32_t)mm; todo_hi = (uint32_t)(mm >> 32);
+        }
+        while (true) {
+            const bool has = (todo_lo | todo_hi) != 0u;
+            if (!__any(has)) break;
+            // deepest entry of this block's mask first
+            const bool in_hi = todo_hi != 0u;
+            const uint32_t word = in_hi ? todo_hi : todo_lo;
+            const int bitpos = 31 - __clz((int)word);                 // -1 when the row has nothing left
+            const uint32_t clr = has ? ~(1u << (bitpos & 31)) : 0xFFFFFFFFu;
+            todo_hi &= in_hi ? clr : 0xFFFFFFFFu;
+            todo_lo &= in_hi ? 0xFFFFFFFFu : clr;
+            const int j = has ? bitpos + (in_hi ? 32 : 0) : 0;
             const int cidx = lo + j;                            // 0-based position in the tile list
             const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
             const float4 a3 = s_rec[j * 5 + 3];
             GsrPair pr;
-            bool active = cidx < last_contributor;
+            bool active = has && cidx < last_contributor;
             if (active) active = gsr_pair_eval(pxf, pyf, a0, a1, a2, a3.z, pr);
-            if (!__any(active)) continue;           // whole wave untouched by this splat
 
             float gT[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float gxy0 = 0.f, gxy1 = 0.f, gn0 = 0.f, gn1 = 0.f, gn2 = 0.f, gopa = 0.f;
             float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f;
             float w_pair = 0.f;   // blending weight of this pair (wide payload: d feature = w * dL/dpixel)
+            // Gaussian id of this row's entry (all lanes must take part in the permute: before `if (active)`)
+            const uint32_t gid = FEAT16 > 0 ? (uint32_t)__shfl((int)id_of_lane, j, 64) : 0u;
             if (active) {
                 const float4 a4 = s_rec[j * 5 + 4];
                 const float alpha = pr.alpha, G = pr.G, c_d = pr.depth;
@@ -195,7 +216,6 @@ GSR_LOAD5(src, cnt * 5);
                     q = c0 * dL_dpix0 + c1 * dL_dpix1 + c2 * dL_dpix2 + c_d * dL_ddepth + dL_daccum
                       + n0 * dL_dn0 + n1 * dL_dn1 + n2 * dL_dn2;
                 } else {
-                    const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id_of_lane, j);   // wave-uniform
                     const float4* f = reinterpret_cast<const float4*>(p.feat + (size_t)gid * p.C);
                     float qc = 0.f;
 #pragma unroll
@@ -256,30 +276,32 @@ GSR_LOAD5(src, cnt * 5);
                 }
             }
 
-            // wave-level sums, stored by the lanes that end up holding them (row layout GSR_GR_*)
+            // block-level sums (16 lanes), stored by the lanes that end up holding them (row layout GSR_GR_*)
             {
                 const float v16[16] = {gT[0], gT[1], gT[2], gT[3], gT[4], gT[5], gT[6], gT[7], gT[8],
                                        gn0, gn1, gn2, gopa, gc0, gc1, gc2};
-                const float tot = wave_sum16_transposed(v16, lane);
-                const float xy = wave_sum2(gxy0, gxy1);
-                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)row_of_lane, j);
-                float* row = p.grad_rows + ((size_t)e * 4 + wave) * RB_ROW;
-                const int vi = lane >> 2;
-                if ((lane & 3) == 0) row[vi < 9 ? vi : vi + 2] = tot;      // skip the two xy columns
-                if (lane == 16) row[GSR_GR_XY] = xy;
-                if (lane == 48) row[GSR_GR_XY + 1] = xy;
-                if (lane == 0) p.row_flags[(size_t)e * 4 + wave] = 1;
-                if (FEAT16 > 0) {   // 16 channels per butterfly; lane 4*c ends up holding channel c of the group
-                    float* frow = p.feat_rows + ((size_t)e * 4 + wave) * p.C;
+                const float tot = row_sum16_transposed(v16, l16);
+                const float xy = row_sum2(gxy0, gxy1, l16);
+                // every row whose to-do bit was set writes its slot (zeros if no pixel turned out active), so
+                // the reduction never reads a row that was not written
+                const uint32_t tw = (uint32_t)__shfl((int)touch_of_lane, j, 64);
+                const size_t slot = (size_t)(uint32_t)__shfl((int)slot_of_lane, j, 64) + __popc(tw & below_mask);
+                if (has) {
+                    float* row = p.grad_rows + slot * RB_ROW;
+                    row[l16 < 9 ? l16 : l16 + 2] = tot;                       // skip the two xy columns
+                    if ((l16 & 7) == 0) row[GSR_GR_XY + (l16 >> 3)] = xy;
+                }
+                if (FEAT16 > 0) {   // 16 channels per butterfly; lane c of the row ends up holding channel c of the group
+                    float* frow = p.feat_rows + slot * p.C;
 #pragma unroll
-                    for (int grp = 0; grp < FEAT16; ++grp) {
-                        if (16 * grp < p.C) {
+                    for (int fg = 0; fg < FEAT16; ++fg) {
+                        if (16 * fg < p.C) {
                             float f16[16];
 #pragma unroll
-                            for (int k = 0; k < 16; ++k) f16[k] = w_pair * dL_dpixf[16 * grp + k];
-                            const float ft = wave_sum16_transposed(f16, lane);
-                            const int ch = 16 * grp + vi;
-                            if ((lane & 3) == 0 && ch < p.C) frow[ch] = ft;
+                            for (int k = 0; k < 16; ++k) f16[k] = w_pair * dL_dpixf[16 * fg + k];
+                            const float ft = row_sum16_transposed(f16, l16);
+                            const int ch = 16 * fg + l16;
+                            if (has && ch < p.C) frow[ch] = ft;
                         }
                     }
                 }
@@ -290,57 +312,68 @@ GSR_LOAD5(src, cnt * 5);
     }
 }
 
-// Wide payload: add a Gaussian's flagged per-(instance, quad) feature sub-rows in fixed order.  One thread per
-// (depth rank, 4-channel piece); writes dL_dcolors [N,C] by Gaussian id (zeros for Gaussians with no instance).
+// Gradient rows are dense: instance e owns rows [slot_off[e], slot_off[e + 1]), one per 4x4 block the forward
+// blended it into.  Count them per instance (touch word -> popcount, scattered to the emission index).
+__global__ void __launch_bounds__(256) slot_count_kernel(int D, const uint32_t* __restrict__ touch,
+                                                         const uint32_t* __restrict__ inst_row,
+                                                         uint32_t* __restrict__ cnt) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos < D) cnt[inst_row[pos]] = (uint32_t)__popc(touch[pos] & 0x0F0F0F0Fu);
+}
+
+int gsr_launch_slot_count(int D, const uint32_t* touch, const uint32_t* inst_row, uint32_t* cnt, hipStream_t s) {
+    if (D <= 0) return GSR_OK;
+    GsrProfileScope prof(GSR_K_SCAN, s);
+    hipLaunchKernelGGL(slot_count_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, D, touch, inst_row, cnt);
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}
+
+// Wide payload: add a Gaussian's feature rows (same dense slots as the geometry rows) in fixed order.  One thread
+// per (depth rank, 4-channel piece); writes dL_dcolors [N,C] by Gaussian id (zeros for Gaussians with no instance).
 __global__ void __launch_bounds__(256) reduce_feat_rows_kernel(long long n_threads, int C4,
                                                                const uint32_t* __restrict__ order,
                                                                const uint32_t* __restrict__ offs,
+                                                               const uint32_t* __restrict__ slot_off,
                                                                const float4* __restrict__ rows,
-                                                               const uint32_t* __restrict__ flags,
                                                                float4* __restrict__ out) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_threads) return;
     const int r = (int)(t / C4), q = (int)(t - (long long)r * C4);
-    const uint32_t e0 = offs[r], e1 = offs[r + 1];
+    const uint32_t s0 = slot_off[offs[r]], s1 = slot_off[offs[r + 1]];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t e = e0; e < e1; ++e) {
-        const uint32_t f = flags[e];
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            if ((f >> (8 * sub)) & 0xFFu) {
-                const float4 v = rows[((size_t)e * 4 + sub) * C4 + q];
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
-        }
+    for (uint32_t sl = s0; sl < s1; ++sl) {
+        const float4 v = rows[(size_t)sl * C4 + q];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     out[(size_t)order[r] * C4 + q] = acc;
 }
 
-int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint32_t* offs, const float* feat_rows,
-                                const uint32_t* row_flags, float* dL_dcolors, hipStream_t s) {
+int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint32_t* offs, const uint32_t* slot_off,
+                                const float* feat_rows, float* dL_dcolors, hipStream_t s) {
     if (N <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_PREPROCESS_BWD, s);
     const int C4 = C / 4;
     const long long n_threads = (long long)N * C4;
     hipLaunchKernelGGL(reduce_feat_rows_kernel, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, s, n_threads, C4,
-                       order, offs, reinterpret_cast<const float4*>(feat_rows), row_flags,
+                       order, offs, slot_off, reinterpret_cast<const float4*>(feat_rows),
                        reinterpret_cast<float4*>(dL_dcolors));
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }
 
 int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* inst_row,
-                          const float* stream, const uint8_t* touch, const float* final_T, const uint32_t* n_contrib,
-                          const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
-                          uint8_t* row_flags, const float* feat, const uint32_t* point_list, float* feat_rows,
-                          hipStream_t s) {
+                          const float* stream, const uint32_t* touch, const uint32_t* slot_off, const float* final_T,
+                          const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
+                          const float* feat, const uint32_t* point_list, float* feat_rows, hipStream_t s) {
     RenderBwdParams p;
     p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
     p.flags = v.flags;
-    p.ranges = ranges; p.inst_row = inst_row; p.stream = reinterpret_cast<const float4*>(stream); p.touch = touch; p.bg = v.bg;
+    p.ranges = ranges; p.inst_row = inst_row; p.stream = reinterpret_cast<const float4*>(stream); p.touch = touch;
+    p.slot_off = slot_off; p.bg = v.bg;
     p.final_T = final_T; p.n_contrib = n_contrib; p.dL_dcolor = dL_dcolor; p.dL_dallmap = dL_dallmap;
-    p.grad_rows = grad_rows; p.row_flags = row_flags;
+    p.grad_rows = grad_rows;
     p.feat = feat; p.point_list = point_list; p.feat_rows = feat_rows; p.C = v.channels;
     if (p.gx <= 0 || gy <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_RENDER_BWD, s);

@@ -46,6 +46,11 @@ struct RenderFwdParams {
 #ifndef RF_MIN_WAVES
 #define RF_MIN_WAVES 8   // <= 64 VGPRs: measured 0.645 -> 0.59 ms at 1M/1080p
 #endif
+template <int CTRL>
+__device__ __forceinline__ uint32_t row_or_step(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
 // FEAT16 = 0: three colour channels taken from the splat record (the reference's configuration).
 // FEAT16 = 1..4: up to 16*FEAT16 feature channels read from `feat` [N,C] by Gaussian id with wave-uniform
 // 16-byte loads (wide per-pixel payload); everything else is identical.
@@ -58,7 +63,9 @@ __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : 2) rend
     float4* s_rec = s_rec_all[wave];
     const int tile_x = blockIdx.x, tile_y = blockIdx.y;
     const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
-    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    // lanes 16g..16g+15 (one DPP row) own the 4x4 pixel block g of the quad: the backward walks per-block lists
+    const int grp = lane >> 4, l16 = lane & 15;
+    const int pxi = qx0 + (grp & 1) * 4 + (l16 & 3), pyi = qy0 + (grp >> 1) * 4 + (l16 >> 2);
     const bool inside = pxi < p.W && pyi < p.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
     const int pix_id = pyi * p.W + pxi;
@@ -92,6 +99,7 @@ GSR_LOAD5(src, lim);
         if (FEAT16 > 0 && lane < min(64, n_list)) pf_id = p.point_list[r0 + lane];
     }
 
+    int covered = 0;   // list entries whose touch byte this wave has written
     for (int base = 0; base < n_list; base += 64) {
         if (__all(done)) break;
         const int nb = min(64, n_list - base);
@@ -157,19 +165,29 @@ GSR_LOAD5(s2, lim);
             const unsigned long long bit = 1ull << j;          // wave-uniform (scalar shift)
             mine_lo |= (uint32_t)bit; mine_hi |= (uint32_t)(bit >> 32);
         }
-        // OR over the 64 pixels, once per batch: which staged splats did this quad blend at all?
+        // OR over the 16 pixels of each 4x4 block (DPP inside a row), once per batch: which staged splats did
+        // this block blend at all?
+        mine_lo |= row_or_step<0xB1>(mine_lo); mine_hi |= row_or_step<0xB1>(mine_hi);     // quad_perm [1,0,3,2]
+        mine_lo |= row_or_step<0x4E>(mine_lo); mine_hi |= row_or_step<0x4E>(mine_hi);     // quad_perm [2,3,0,1]
+        mine_lo |= row_or_step<0x141>(mine_lo); mine_hi |= row_or_step<0x141>(mine_hi);   // row_half_mirror
+        mine_lo |= row_or_step<0x140>(mine_lo); mine_hi |= row_or_step<0x140>(mine_hi);   // row_mirror
+        // one byte per (instance, quad) for the backward, bit g = "block g blended it": lane j reports staged splat j
+        // (the readlanes stay outside the `lane < nb` branch: lanes 16g must be active when they are read)
+        uint32_t byte = 0;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            mine_lo |= (uint32_t)__shfl_xor((int)mine_lo, d, 64);
-            mine_hi |= (uint32_t)__shfl_xor((int)mine_hi, d, 64);
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)mine_lo, 16 * g);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)mine_hi, 16 * g);
+            byte |= (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) << g;
         }
-        // one byte per (instance, quad) for the backward: lane j reports staged splat j
-        if (lane < nb) {
-            const uint32_t word = lane < 32 ? mine_lo : mine_hi;
-            p.touch[((size_t)r0 + base + lane) * 4 + wave] = (uint8_t)((word >> (lane & 31)) & 1u);
-        }
+        if (lane < nb) p.touch[((size_t)r0 + base + lane) * 4 + wave] = (uint8_t)byte;
+        covered = base + nb;
         __builtin_amdgcn_wave_barrier();   // all reads of this batch precede the next batch's LDS writes
     }
+
+    // entries behind the point where every pixel saturated were never staged: nothing was blended there
+    // (the backward sizes its gradient rows from these bytes, so they must all be defined)
+    for (int pos = covered + lane; pos < n_list; pos += 64) p.touch[((size_t)r0 + pos) * 4 + wave] = 0;
 
     if (inside) {
         p.final_T[pix_id] = T;

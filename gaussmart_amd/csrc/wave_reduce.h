@@ -52,3 +52,38 @@ __device__ __forceinline__ float wave_sum2(float a, float b) {
     return v;
 }
 
+
+// ---- 16-lane (one DPP row) reductions: no cross-row traffic at all ------------------------------------
+// Transposed butterfly over the 16 lanes of a row: 8 + 4 + 2 + 1 adds, each fused with its DPP move.
+// On return lane l (0..15 inside its row) holds the ROW total of v[l].
+__device__ __forceinline__ float row_sum16_transposed(const float (&v)[16], int l16) {
+    const bool b3 = (l16 & 8) != 0, b2 = (l16 & 4) != 0, b1 = (l16 & 2) != 0, b0 = (l16 & 1) != 0;
+    float r[8], q[4], p[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {      // bit 3: partner is lane ^ 8 (row_ror:8)
+        const float keep = b3 ? v[i + 8] : v[i], send = b3 ? v[i] : v[i + 8];
+        r[i] = keep + dpp_move<0x128, 0xf>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {      // bit 2: partner is lane ^ 7 (row_half_mirror); it keeps the other half
+        const float keep = b2 ? r[i + 4] : r[i], send = b2 ? r[i] : r[i + 4];
+        q[i] = keep + dpp_move<0x141, 0xf>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {      // bit 1: partner is lane ^ 2 (quad_perm [2,3,0,1])
+        const float keep = b1 ? q[i + 2] : q[i], send = b1 ? q[i] : q[i + 2];
+        p[i] = keep + dpp_move<0x4E, 0xf>(send);
+    }
+    const float keep = b0 ? p[1] : p[0], send = b0 ? p[0] : p[1];
+    return keep + dpp_move<0xB1, 0xf>(send);   // bit 0: partner is lane ^ 1 (quad_perm [1,0,3,2])
+}
+// Two values: on return lanes 0..7 of the row hold the row total of a, lanes 8..15 that of b.
+__device__ __forceinline__ float row_sum2(float a, float b, int l16) {
+    const bool b3 = (l16 & 8) != 0;
+    const float keep = b3 ? b : a, send = b3 ? a : b;
+    float v = keep + dpp_move<0x128, 0xf>(send);
+    v += dpp_move<0xB1, 0xf>(v);
+    v += dpp_move<0x4E, 0xf>(v);
+    v += dpp_move<0x141, 0xf>(v);   // row_half_mirror: every lane of the 8 holds their sum
+    return v;
+}

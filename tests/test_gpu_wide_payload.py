@@ -36,8 +36,8 @@ def test_wide_payload_forward_backward_parity(gpu_device, C, n, w, h):
 
 def test_wide_payload_first_three_channels_equal_rgb_path(gpu_device):
     """Channels 0..2 of a wide payload must be bit-identical to the RGB kernel fed the same three
-    columns (same pairs, same order, same fp32 operations) and so must their gradient; the geometry
-    gradients agree to rounding (the wide kernel adds the colour term of q in a different order)."""
+    columns (same pairs, same order, same fp32 operations); all gradients agree to rounding (the wide
+    kernel adds the colour term of q, and the sub-rows of the feature gradient, in a different order)."""
     from gaussmart_amd.rasterizer import GaussianRasterizer
     b, cam, bg = _wide_inputs(3000, 320, 200, 8, seed=5)
     dev = gpu_device
@@ -59,7 +59,8 @@ def test_wide_payload_first_three_channels_equal_rgb_path(gpu_device):
     c8, am8, r8, g8, gc8, m8 = run(b["colors_precomp"], bg)
     c3, am3, r3, g3, gc3, m3 = run(b["colors_precomp"][:, :3].contiguous(), bg[:3])
     assert torch.equal(c8[:3], c3) and torch.equal(am8, am3) and torch.equal(r8, r3)
-    assert torch.equal(gc8[:, :3], gc3)
+    # feature gradients are summed over the sub-rows in a different (fixed) order than the RGB columns
+    assert float((gc8[:, :3] - gc3).abs().max()) < 1e-5 * float(gc3.abs().max())
     assert float(gc8[:, 3:].abs().max()) == 0.0
     g8["means2D"], g3["means2D"] = m8, m3
     for k in g3:
