@@ -53,7 +53,7 @@ class MiniCam:
         self.znear, self.zfar = znear, zfar
         self.world_view_transform = world_view_transform
         self.full_proj_transform = full_proj_transform
-        self.camera_center = torch.inverse(world_view_transform)[3][:3]
+        self.camera_center = torch.inverse(world_view_transform)[3][:3].contiguous()
 
 
 class Camera(torch.nn.Module):
@@ -75,10 +75,10 @@ class Camera(torch.nn.Module):
         self.zfar, self.znear = ZFAR, ZNEAR
         self.trans, self.scale = trans, scale
         dev = self.data_device
-        self.world_view_transform = torch.tensor(getWorld2View2(R, T, trans, scale)).transpose(0, 1).to(dev)
+        self.world_view_transform = torch.tensor(getWorld2View2(R, T, trans, scale)).transpose(0, 1).contiguous().to(dev)
         self.projection_matrix = getProjectionMatrix(self.znear, self.zfar, FoVx, FoVy).transpose(0, 1).to(dev)
         self.full_proj_transform = self.world_view_transform @ self.projection_matrix
-        self.camera_center = self.world_view_transform.inverse()[3, :3]
+        self.camera_center = self.world_view_transform.inverse()[3, :3].contiguous()
 
 
 def look_at_camera(eye, target, up, fovx, width, height, device="cpu", image=None, uid=0):

@@ -38,10 +38,13 @@ class _PhotometricLoss(torch.autograd.Function):
         ctx.save_for_backward(img, tgt, maps)
         ctx.lambda_dssim = float(lambda_dssim)
         ctx.mark_non_differentiable(l1, ssim)
+        ctx.set_materialize_grads(False)
         return loss, l1, ssim
 
     @staticmethod
     def backward(ctx, g_loss, _g_l1, _g_ssim):
+        if g_loss is None:
+            return None, None, None
         L = _lib.lib()
         img, tgt, maps = ctx.saved_tensors
         Cn, H, W = img.shape

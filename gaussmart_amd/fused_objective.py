@@ -54,10 +54,13 @@ class _Objective(torch.autograd.Function):
             ctx.save_for_backward(img, tgt, maps)
         total, parts = out[0], out[1:]
         ctx.mark_non_differentiable(parts)
+        ctx.set_materialize_grads(False)
         return total, parts
 
     @staticmethod
     def backward(ctx, g_total, _g_parts):
+        if g_total is None:
+            return (None,) * 8
         L = _lib.lib()
         saved = ctx.saved_tensors
         img, tgt, maps = saved[0], saved[1], saved[2]

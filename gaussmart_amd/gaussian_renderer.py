@@ -79,11 +79,9 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
            surface_maps=True):
     xyz = pc.get_xyz
     device = xyz.device
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # the reference adds 0 and calls retain_grad() (gaussian_renderer/__init__.py:27-31); a leaf that requires
+    # grad receives the same .grad without the extra add and the gradient clone of retain_grad
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=device)
 
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)

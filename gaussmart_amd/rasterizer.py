@@ -182,11 +182,16 @@ def release_workspace():
     _POOL.clear()
 
 
-def _make_view(rs: GaussianRasterizationSettings, sh_coeffs: int, flags: int, device, channels: int = 3):
-    bg = _f32c(rs.bg, "bg", device)
-    vm = _f32c(rs.viewmatrix, "viewmatrix", device)
-    pm = _f32c(rs.projmatrix, "projmatrix", device)
-    cp = _f32c(rs.campos, "campos", device)
+def _make_view(rs: GaussianRasterizationSettings, sh_coeffs: int, flags: int, device, channels: int = 3, keep=None):
+    """GsrView + the tensors its pointers refer to.  `keep` = the tuple a previous call returned for the same
+    settings (the backward reuses the forward's contiguous copies instead of making them again)."""
+    if keep is not None:
+        bg, vm, pm, cp = keep
+    else:
+        bg = _f32c(rs.bg, "bg", device)
+        vm = _f32c(rs.viewmatrix, "viewmatrix", device)
+        pm = _f32c(rs.projmatrix, "projmatrix", device)
+        cp = _f32c(rs.campos, "campos", device)
     if bg.numel() != channels or vm.numel() != 16 or pm.numel() != 16 or cp.numel() != 3:
         raise ValueError(f"bg must have {channels} elements (one per output channel), campos 3, "
                          "viewmatrix/projmatrix 16")
@@ -245,6 +250,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.flags = flags
         ctx.num_rendered = int(out.num_rendered)
         ctx.view_keep = keep
+        ctx.set_materialize_grads(False)     # no zero tensors for the unused radii / image gradients
         ctx.none_mask = (sh is None, colors_precomp is None, scales is None, cov3Ds_precomp is None)
         geom = alloc.buffers[_lib.GSR_BUF_GEOM]
         binning = alloc.buffers[_lib.GSR_BUF_BINNING]
@@ -281,7 +287,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             torch.zeros((7, H, W), device=device)
 
         with torch.cuda.device(device):
-            view, keep = _make_view(rs, sh.shape[1] if sh is not None else 0, ctx.flags, device, ctx.channels)
+            view, keep = _make_view(rs, sh.shape[1] if sh is not None else 0, ctx.flags, device, ctx.channels, ctx.view_keep)
             g = _lib.GsrGaussians(N, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities),
                                   _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp), None)
             d_means3D = torch.empty_like(means3D)
@@ -348,6 +354,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             _lib.check(rc)
         ctx.lease = alloc.kept
         ctx.raster_settings, ctx.flags, ctx.num_rendered, ctx.M = rs, flags, int(out.num_rendered), M
+        ctx.view_keep = keep
+        ctx.set_materialize_grads(False)     # no zero tensors for the unused radii / image gradients
         ctx.save_for_backward(xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, radii,
                               alloc.buffers[_lib.GSR_BUF_GEOM], alloc.buffers[_lib.GSR_BUF_BINNING],
                               alloc.buffers[_lib.GSR_BUF_IMAGE])
@@ -368,7 +376,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         grad_allmap = _f32c(grad_allmap, "grad_allmap", device) if grad_allmap is not None else torch.zeros((7, H, W), device=device)
         rest = f_rest if f_rest.shape[1] > 0 else None
         with torch.cuda.device(device):
-            view, keep = _make_view(rs, ctx.M, ctx.flags, device)
+            view, keep = _make_view(rs, ctx.M, ctx.flags, device, 3, ctx.view_keep)
             g = _lib.GsrGaussians(N, _ptr(xyz), _ptr(f_dc), None, _ptr(opacity_raw), _ptr(scaling_raw),
                                   _ptr(rotation_raw), None, _ptr(rest) if rest is not None else None)
             d_xyz, d_2d = torch.empty_like(xyz), torch.empty((N, 3), dtype=torch.float32, device=device)

@@ -29,6 +29,17 @@ def photometric(image, gt_image, lambda_dssim):
     return (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - ssim(image, gt_image)), Ll1
 
 
+_UNIT = {}
+
+
+def _unit_gradient(t):
+    key = (t.device, t.dtype)
+    one = _UNIT.get(key)
+    if one is None:
+        one = _UNIT[key] = torch.ones((), device=t.device, dtype=t.dtype)
+    return one
+
+
 def training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam=None, pipe=None):
     """train.py:113-143.  On a HIP device the whole objective (L1 + SSIM + surface regularizers) is
     one fused autograd node (gaussmart_amd/fused_objective.py); on the host (CPU plumbing tests)
@@ -57,7 +68,7 @@ def training_step(gaussians, viewpoint_cam, gt_image, opt, pipe, background, ite
     on_device = gaussians.get_xyz.is_cuda
     render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=not on_device)
     total, parts = training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam, pipe)
-    total.backward()
+    total.backward(gradient=_unit_gradient(total))   # cached: saves the ones_like() fill of every step
     if view_parallel is not None:
         view_parallel.allreduce_gradients()
     if step_optimizer:
