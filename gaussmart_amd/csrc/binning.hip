@@ -63,20 +63,6 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_reduce_kernel(const uint32_t*
     if (threadIdx.x == 0) partial[blockIdx.x] = wt[0] + wt[1] + wt[2] + wt[3];
 }
 
-// single block: exclusive scan of the block partials in place
-__global__ void __launch_bounds__(SCAN_BLOCK) scan_partials_kernel(uint32_t* __restrict__ partial, int n) {
-    __shared__ uint32_t wt[SCAN_BLOCK / 64];
-    uint32_t carry = 0;
-    for (int base = 0; base < n; base += SCAN_BLOCK) {
-        const int j = base + threadIdx.x;
-        const uint32_t v = j < n ? partial[j] : 0;
-        uint32_t total;
-        const uint32_t ex = block_excl_scan(v, total, wt);
-        if (j < n) partial[j] = carry + ex;
-        carry += total;
-    }
-}
-
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const uint32_t* __restrict__ in,
                                                                 const uint32_t* __restrict__ gather,
                                                                 const uint32_t* __restrict__ partial,
@@ -92,8 +78,13 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const uint32_t* 
         v[i] = j < n ? (gather ? in[gather[j]] : in[j]) : 0;
         tsum += v[i];
     }
-    uint32_t total;
-    uint32_t run = partial[blockIdx.x] + block_excl_scan(tsum, total, wt);
+    // offset of this tile = sum of the preceding tiles' totals (<= a few thousand values: cheaper than a
+    // third launch that scans them)
+    uint32_t pre = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_BLOCK) pre += partial[j];
+    uint32_t tile_offset, total;
+    (void)block_excl_scan(pre, tile_offset, wt);
+    uint32_t run = tile_offset + block_excl_scan(tsum, total, wt);
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         const int64_t j = first + i;
@@ -119,7 +110,6 @@ int gsr_exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t*
     uint32_t* partial = static_cast<uint32_t*>(ws);
     const int blocks = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, s, in, gather, partial, n);
-    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, partial, blocks);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, s, in, gather, partial, out, n);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
@@ -316,44 +306,80 @@ int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint3
 }
 
 // ============================================================================ emit / finalize
-__global__ void __launch_bounds__(256) emit_instances_kernel(int N, int gx, int gy,
+// Tile rects in depth-rank order: ONE gather by Gaussian id; the scan of the counts and the emission below then
+// read everything coalesced (before, the scan gathered tiles_touched twice and emit gathered four arrays).
+__global__ void __launch_bounds__(256) rank_gather_kernel(int N, const uint32_t* __restrict__ order,
+                                                          const uint2* __restrict__ tile_rect,
+                                                          uint2* __restrict__ rank_rect,
+                                                          uint32_t* __restrict__ rank_cnt) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const uint2 R = tile_rect[order[r]];
+    rank_rect[r] = R;
+    rank_cnt[r] = (R.y & 0xFFFFu) * (R.y >> 16);
+}
+
+int gsr_launch_rank_gather(int N, const uint32_t* order, const uint2* tile_rect, uint2* rank_rect, uint32_t* rank_cnt,
+                           hipStream_t s) {
+    if (N <= 0) return GSR_OK;
+    GsrProfileScope prof(GSR_K_EMIT, s);
+    hipLaunchKernelGGL(rank_gather_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, order, tile_rect, rank_rect, rank_cnt);
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}
+
+// Load-balanced expansion: a wave owns 64 consecutive depth ranks, whose instances are one contiguous output
+// range.  Lane k parks rank k's (first output index, Gaussian id, tile rect) in LDS; then the 64 lanes fill the
+// range 64 outputs at a time, each finding its owner by binary search over the 64 first-indices -- the three
+// output streams are written fully coalesced however unequal the rects are.
+__global__ void __launch_bounds__(256) emit_instances_kernel(int N, int gx,
                                                              const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ offs,
-                                                             const float* __restrict__ splat,
-                                                             const int32_t* __restrict__ radii,
-                                                             const uint32_t* __restrict__ tiles_touched,
-                                                             uint32_t* __restrict__ inst_begin,
+                                                             const uint2* __restrict__ rank_rect,
                                                              uint32_t* __restrict__ tile_keys,
                                                              uint32_t* __restrict__ inst_vals,
                                                              uint32_t* __restrict__ emit_gid) {
+    __shared__ uint32_t s_off[4][64], s_gid[4][64], s_xy[4][64], s_w[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;   // depth rank
-    if (r >= N) return;
-    const uint32_t g = order[r];
-    const uint32_t cnt = tiles_touched[g];
-    uint32_t off = offs[r];
-    inst_begin[g] = off;
-    if (cnt == 0) return;
-    const float cx = splat[(size_t)g * GSR_SPLAT_FLOATS + GSR_SP_XY];
-    const float cy = splat[(size_t)g * GSR_SPLAT_FLOATS + GSR_SP_XY + 1];
-    int x0, y0, x1, y1;
-    gsr_tile_rect(cx, cy, radii[g], gx, gy, x0, y0, x1, y1);
-    for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) {
-            tile_keys[off] = (uint32_t)(y * gx + x);
-            inst_vals[off] = off;
-            emit_gid[off] = g;
-            ++off;
-        }
+    uint32_t off = 0xFFFFFFFFu, g = 0, xy = 0, w = 1;
+    if (r < N) {
+        g = order[r];
+        off = offs[r];
+        const uint2 R = rank_rect[r];
+        xy = R.x;
+        w = max(1u, R.y & 0xFFFFu);
+    }
+    s_off[wave][lane] = off; s_gid[wave][lane] = g; s_xy[wave][lane] = xy; s_w[wave][lane] = w;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int wave_first = blockIdx.x * blockDim.x + wave * 64;
+    if (wave_first >= N) return;
+    const int wave_last = min(N, wave_first + 64);                  // exclusive
+    const uint32_t begin = offs[wave_first], end = offs[wave_last]; // offs has N + 1 entries
+    for (uint32_t o = begin + lane; o < end; o += 64) {
+        // owner = last rank k of the wave with s_off[k] <= o (ranks without instances share their successor's
+        // first index, so "last" skips them; lanes beyond N hold 0xFFFFFFFF)
+        int k = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+            if (s_off[wave][k + step] <= o) k += step;
+        const uint32_t i = o - s_off[wave][k], ww = s_w[wave][k], c = s_xy[wave][k];
+        const uint32_t row = i / ww, col = i - row * ww;
+        tile_keys[o] = ((c >> 16) + row) * (uint32_t)gx + (c & 0xFFFFu) + col;
+        inst_vals[o] = o;
+        emit_gid[o] = s_gid[wave][k];
+    }
 }
 
 int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const uint32_t* offs,
-                    const float* splat, const int32_t* radii, const uint32_t* tiles_touched,
-                    uint32_t* inst_begin, uint32_t* tile_keys, uint32_t* inst_vals,
+                    const uint2* rank_rect, uint32_t* tile_keys, uint32_t* inst_vals,
                     uint32_t* emit_gid, hipStream_t s) {
     if (N <= 0) return GSR_OK;
+    (void)grid_y;
     GsrProfileScope prof(GSR_K_EMIT, s);
-    hipLaunchKernelGGL(emit_instances_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, grid_x, grid_y,
-                       order, offs, splat, radii, tiles_touched, inst_begin, tile_keys, inst_vals, emit_gid);
+    hipLaunchKernelGGL(emit_instances_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, grid_x,
+                       order, offs, rank_rect, tile_keys, inst_vals, emit_gid);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

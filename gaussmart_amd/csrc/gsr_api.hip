@@ -168,14 +168,14 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     float* splat = at<float>(geom, GL.splat);
     uint32_t* clamped = at<uint32_t>(geom, GL.clamped);
     uint32_t* tiles_touched = at<uint32_t>(geom, GL.tiles_touched);
-    uint32_t* inst_begin = at<uint32_t>(geom, GL.inst_begin);
+    uint2* tile_rect = at<uint2>(geom, GL.tile_rect);
     uint32_t* depth_key = at<uint32_t>(geom, GL.depth_key);
 
     // N-sized scratch: depth-sort double buffers, sort + scan workspaces
     const size_t nb = gsr_align(size_t(N > 0 ? N : 1) * 4);
     const size_t sort_ws_n = gsr_sort_ws_bytes(N);
     const size_t scan_ws_n = gsr_scan_workspace_bytes(N);
-    const size_t scratch_bytes = 3 * nb + sort_ws_n + scan_ws_n;
+    const size_t scratch_bytes = 4 * nb + sort_ws_n + scan_ws_n;
     char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, scratch_bytes));
     if (!scratch) { gsr_set_error("allocator returned NULL (scratch)"); return GSR_E_ALLOC; }
     uint32_t* keys_sorted = reinterpret_cast<uint32_t*>(scratch);
@@ -183,17 +183,22 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     uint32_t* vals_tmp = reinterpret_cast<uint32_t*>(scratch + 2 * nb);
     uint32_t* order = at<uint32_t>(geom, GL.order);     // kept for the backward's row reduction
     uint32_t* offs = at<uint32_t>(geom, GL.offs);
-    void* sort_ws = scratch + 3 * nb;
+    // after the depth sort its double buffers are free: they hold the rank-ordered tile rects and counts
+    uint32_t* rank_cnt = keys_tmp;
+    uint2* rank_rect = reinterpret_cast<uint2*>(scratch + 2 * nb);   // 2 nb: vals_tmp + the 4th block
+    void* sort_ws = scratch + 4 * nb;
     void* scan_ws = static_cast<char*>(sort_ws) + sort_ws_n;
 
     uint32_t D = 0;
     if (N > 0) {
-        rc = gsr_launch_preprocess_fwd(*view, *g, splat, clamped, tiles_touched, depth_key, out->radii, s);
+        rc = gsr_launch_preprocess_fwd(*view, *g, splat, clamped, tiles_touched, tile_rect, depth_key, out->radii, s);
         if (rc != GSR_OK) return rc;
         // depth order of the Gaussians (stable; culled ones carry key 0xFFFFFFFF and no tiles)
         rc = gsr_radix_sort_pairs(depth_key, nullptr, keys_sorted, order, keys_tmp, vals_tmp, N, 0, 32, sort_ws, s);
         if (rc != GSR_OK) return rc;
-        rc = gsr_exclusive_scan_u32(tiles_touched, order, offs, N, scan_ws, s);
+        rc = gsr_launch_rank_gather(N, order, tile_rect, rank_rect, rank_cnt, s);
+        if (rc != GSR_OK) return rc;
+        rc = gsr_exclusive_scan_u32(rank_cnt, nullptr, offs, N, scan_ws, s);
         if (rc != GSR_OK) return rc;
         // The instance count sizes the next buffers, so the host has to see it: the copy is followed by
         // an event, and the SH colour pass is enqueued BEHIND that event so that it runs during the
@@ -232,7 +237,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         uint32_t* tk_tmp = reinterpret_cast<uint32_t*>(sc2 + 5 * db);
         uint32_t* tv_tmp = reinterpret_cast<uint32_t*>(sc2 + 6 * db);
         void* sort_ws2 = sc2 + 7 * db;
-        rc = gsr_launch_emit(N, gx, gy, order, offs, splat, out->radii, tiles_touched, inst_begin,
+        rc = gsr_launch_emit(N, gx, gy, order, offs, rank_rect,
                              tile_keys, inst_vals, emit_gid, s);
         if (rc != GSR_OK) return rc;
         rc = gsr_radix_sort_pairs(tile_keys, inst_vals, tile_sorted, perm, tk_tmp, tv_tmp, D, 0,
@@ -343,7 +348,6 @@ extern "C" int32_t gsr_buffer_field(int32_t which, const char* name, int32_t N, 
         if (!strcmp(name, "splat")) { *offset = L.splat; *bytes = size_t(N) * GSR_SPLAT_FLOATS * 4; return GSR_OK; }
         if (!strcmp(name, "clamped")) { *offset = L.clamped; *bytes = size_t(N) * 4; return GSR_OK; }
         if (!strcmp(name, "tiles_touched")) { *offset = L.tiles_touched; *bytes = size_t(N) * 4; return GSR_OK; }
-        if (!strcmp(name, "inst_begin")) { *offset = L.inst_begin; *bytes = size_t(N) * 4; return GSR_OK; }
         if (!strcmp(name, "depth_key")) { *offset = L.depth_key; *bytes = size_t(N) * 4; return GSR_OK; }
         if (!strcmp(name, "order")) { *offset = L.order; *bytes = size_t(N) * 4; return GSR_OK; }
         if (!strcmp(name, "offs")) { *offset = L.offs; *bytes = size_t(N + 1) * 4; return GSR_OK; }

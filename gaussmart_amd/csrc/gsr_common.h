@@ -64,13 +64,13 @@ struct GsrProfileScope {
 static inline size_t gsr_align(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct GsrGeomLayout {
-    size_t splat, clamped, tiles_touched, inst_begin, depth_key, order, offs, total;
+    size_t splat, clamped, tiles_touched, tile_rect, depth_key, order, offs, total;
     explicit GsrGeomLayout(int64_t N) {
         size_t o = 0;
         splat = o;         o += gsr_align(size_t(N) * GSR_SPLAT_FLOATS * 4);
         clamped = o;       o += gsr_align(size_t(N) * 4);
         tiles_touched = o; o += gsr_align(size_t(N) * 4);
-        inst_begin = o;    o += gsr_align(size_t(N) * 4);
+        tile_rect = o;     o += gsr_align(size_t(N) * 8);        // (x0 | y0 << 16, w | h << 16) on the tile grid
         depth_key = o;     o += gsr_align(size_t(N) * 4);
         order = o;         o += gsr_align(size_t(N) * 4);        // depth rank -> Gaussian id
         offs = o;          o += gsr_align(size_t(N + 1) * 4);    // depth rank -> first instance (emission order)
@@ -116,13 +116,14 @@ int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint3
 
 // ---------------------------------------------------------------- kernel launchers
 int gsr_launch_preprocess_fwd(const GsrView& v, const GsrGaussians& g, float* splat,
-                              uint32_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key,
+                              uint32_t* clamped, uint32_t* tiles_touched, uint2* tile_rect, uint32_t* depth_key,
                               int32_t* radii, hipStream_t s);
 int gsr_launch_preprocess_color(const GsrView& v, const GsrGaussians& g, float* splat, uint32_t* clamped,
                                 int32_t* radii, hipStream_t s);
+int gsr_launch_rank_gather(int N, const uint32_t* order, const uint2* tile_rect, uint2* rank_rect, uint32_t* rank_cnt,
+                           hipStream_t s);
 int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const uint32_t* offs,
-                    const float* splat, const int32_t* radii, const uint32_t* tiles_touched,
-                    uint32_t* inst_begin, uint32_t* tile_keys, uint32_t* inst_vals,
+                    const uint2* rank_rect, uint32_t* tile_keys, uint32_t* inst_vals,
                     uint32_t* emit_gid, hipStream_t s);
 int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted,
                              const uint32_t* perm, const uint32_t* emit_gid, const float* splat,

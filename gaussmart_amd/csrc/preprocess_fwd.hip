@@ -22,7 +22,7 @@ struct PreParams {
     bool raw;
     const float* means; const float* shs; const float* shs_rest; const float* colors; const float* opac;
     const float* scales; const float* rots; const float* tprecomp;
-    float* splat; uint32_t* clamped; uint32_t* tiles; uint32_t* dkey; int32_t* radii;
+    float* splat; uint32_t* clamped; uint32_t* tiles; uint2* rect; uint32_t* dkey; int32_t* radii;
 };
 
 __device__ __forceinline__ float3 sh_to_rgb(int deg, const float* sh /*[M][3] in LDS or global*/,
@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
     // defaults for a culled Gaussian
     p.radii[idx] = 0;
     p.tiles[idx] = 0;
+    if (p.rect) p.rect[idx] = make_uint2(0u, 0u);
     p.dkey[idx] = 0xFFFFFFFFu;
 
     const float* V = p.view;
@@ -218,6 +219,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
     p.clamped[idx] = clamp_bits;
     p.radii[idx] = (int)radius;
     p.tiles[idx] = (uint32_t)ntiles;
+    if (p.rect) p.rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16));
     p.dkey[idx] = __float_as_uint(vz);
 }
 
@@ -251,7 +253,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_color_kernel(PreParams p
 }
 
 static void fill_pre_params(PreParams& p, const GsrView& v, const GsrGaussians& g, float* splat, uint32_t* clamped,
-                            uint32_t* tiles_touched, uint32_t* depth_key, int32_t* radii) {
+                            uint32_t* tiles_touched, uint2* tile_rect, uint32_t* depth_key, int32_t* radii) {
     p.N = g.count; p.W = v.width; p.H = v.height;
     p.gx = (v.width + GSR_TILE - 1) / GSR_TILE; p.gy = (v.height + GSR_TILE - 1) / GSR_TILE;
     p.deg = v.sh_degree; p.M = v.sh_coeffs; p.mod = v.scale_modifier;
@@ -259,14 +261,14 @@ static void fill_pre_params(PreParams& p, const GsrView& v, const GsrGaussians& 
     p.raw = (v.flags & (uint32_t)GSR_FLAG_RAW_PARAMS) != 0;
     p.means = g.means3D; p.shs = g.shs; p.shs_rest = g.shs_rest; p.colors = v.channels == 3 ? g.colors_precomp : nullptr /* wide payloads are read by id in K6/K7 */; p.opac = g.opacities;
     p.scales = g.scales; p.rots = g.rotations; p.tprecomp = g.transmat_precomp;
-    p.splat = splat; p.clamped = clamped; p.tiles = tiles_touched; p.dkey = depth_key; p.radii = radii;
+    p.splat = splat; p.clamped = clamped; p.tiles = tiles_touched; p.rect = tile_rect; p.dkey = depth_key; p.radii = radii;
 }
 
 int gsr_launch_preprocess_color(const GsrView& v, const GsrGaussians& g, float* splat, uint32_t* clamped,
                                 int32_t* radii, hipStream_t s) {
     if (g.count <= 0 || g.shs == nullptr) return GSR_OK;
     PreParams p;
-    fill_pre_params(p, v, g, splat, clamped, nullptr, nullptr, radii);
+    fill_pre_params(p, v, g, splat, clamped, nullptr, nullptr, nullptr, radii);
     const int blocks = (g.count + PRE_BLOCK - 1) / PRE_BLOCK;
     GsrProfileScope prof(GSR_K_PREPROCESS_FWD, s);
     const bool stage = sh_can_stage(g.shs, g.shs_rest, v.sh_coeffs);
@@ -283,11 +285,11 @@ int gsr_launch_preprocess_color(const GsrView& v, const GsrGaussians& g, float* 
 
 // Geometry part of K1 (everything except the SH colour; precomputed colours are copied here).
 int gsr_launch_preprocess_fwd(const GsrView& v, const GsrGaussians& g, float* splat,
-                              uint32_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key,
+                              uint32_t* clamped, uint32_t* tiles_touched, uint2* tile_rect, uint32_t* depth_key,
                               int32_t* radii, hipStream_t s) {
     if (g.count <= 0) return GSR_OK;
     PreParams p;
-    fill_pre_params(p, v, g, splat, clamped, tiles_touched, depth_key, radii);
+    fill_pre_params(p, v, g, splat, clamped, tiles_touched, tile_rect, depth_key, radii);
     const int blocks = (g.count + PRE_BLOCK - 1) / PRE_BLOCK;
     GsrProfileScope prof(GSR_K_PREPROCESS_FWD, s);
     hipLaunchKernelGGL((preprocess_fwd_kernel<false, false>), dim3(blocks), dim3(PRE_BLOCK), 0, s, p);

@@ -468,8 +468,8 @@ def rasterize_debug(means3D, opacities, shs=None, colors_precomp=None, scales=No
     res = dict(color=color, allmap=allmap, radii=radii, num_rendered=D, _lease=alloc.kept)
     spec = {
         _lib.GSR_BUF_GEOM: [("splat", torch.float32, (N, 20)), ("clamped", torch.int32, (N,)),
-                            ("tiles_touched", torch.int32, (N,)), ("inst_begin", torch.int32, (N,)),
-                            ("depth_key", torch.int32, (N,))],
+                            ("tiles_touched", torch.int32, (N,)), ("depth_key", torch.int32, (N,)),
+                            ("order", torch.int32, (N,)), ("offs", torch.int32, (N + 1,))],
         _lib.GSR_BUF_BINNING: [("point_list", torch.int32, (D,)), ("inst_row", torch.int32, (D,)),
                                ("ranges", torch.int32, (-1, 2))],
         _lib.GSR_BUF_IMAGE: [("final_T", torch.float32, (3, H, W)), ("n_contrib", torch.int32, (2, H, W))],
@@ -480,5 +480,8 @@ def rasterize_debug(means3D, opacities, shs=None, colors_precomp=None, scales=No
             off, nbytes = _lib.buffer_field(which, name, N, D, W, H)
             res[name] = buf[off:off + nbytes].view(dt).reshape(shape) if nbytes else \
                 torch.empty(0, dtype=dt, device=device).reshape([s if s >= 0 else 0 for s in shape])
+    # first emission index of every Gaussian (depth rank r = order^-1): offs is indexed by rank
+    res["inst_begin"] = torch.zeros(N, dtype=torch.int32, device=device)
+    res["inst_begin"][res["order"].long()] = res["offs"][:N]
     del keep
     return res
