@@ -189,23 +189,27 @@ GSR_LOAD5(src, cnt * 5);
             const int cidx = lo + j;                            // 0-based position in the tile list
             const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
             const float4 a3 = s_rec[j * 5 + 3];
+            // Branch-free: EVERY lane runs the gradient math (masked-off lanes would cost the same issue slots),
+            // and a lane that does not blend this splat gets alpha = G = 0 and harmless finite geometry, which
+            // makes all 18 of its partial derivatives exact zeros and leaves its recursion state untouched
+            // (T / (1 - 0) = T; the suffix sums advance by a zero-weight term).
             GsrPair pr;
-            bool active = has && cidx < last_contributor;
-            if (active) active = gsr_pair_eval(pxf, pyf, a0, a1, a2, a3.z, pr);
-
-            float gT[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            float gxy0 = 0.f, gxy1 = 0.f, gn0 = 0.f, gn1 = 0.f, gn2 = 0.f, gopa = 0.f;
-            float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f;
-            float w_pair = 0.f;   // blending weight of this pair (wide payload: d feature = w * dL/dpixel)
-            // Gaussian id of this row's entry (all lanes must take part in the permute: before `if (active)`)
+            const bool ok = gsr_pair_eval(pxf, pyf, a0, a1, a2, a3.z, pr);
+            const bool active = has && cidx < last_contributor && ok;
+            // Gaussian id of this row's entry (wide payload)
             const uint32_t gid = FEAT16 > 0 ? (uint32_t)__shfl((int)id_of_lane, j, 64) : 0u;
-            if (active) {
+            float gT[9];
+            float gxy0, gxy1, gn0, gn1, gn2, gopa, gc0, gc1, gc2;
+            float w_pair;   // blending weight of this pair (wide payload: d feature = w * dL/dpixel)
+            {
                 const float4 a4 = s_rec[j * 5 + 4];
-                const float alpha = pr.alpha, G = pr.G, c_d = pr.depth;
+                const float alpha = active ? pr.alpha : 0.f, G = active ? pr.G : 0.f, c_d = active ? pr.depth : 1.f;
+                const float sx = active ? pr.sx : 0.f, sy = active ? pr.sy : 0.f, inv_pz = active ? pr.inv_pz : 0.f;
                 const float one_m_alpha = 1.0f - alpha;
                 const float inv_oma = gsr_rcp(one_m_alpha);
                 T = T * inv_oma;
                 const float w = alpha * T;
+                w_pair = w;
 
                 // colour, expected depth, alpha and normal share one suffix recursion:
                 //   q_i = c_i . dL/dC + z_i dL/dD + 1 dL/dA + n_i . dL/dN
@@ -226,7 +230,6 @@ GSR_LOAD5(src, cnt * 5);
                         }
                     }
                     q += qc;
-                    w_pair = w;
                 }
                 acc_q = last_alpha * last_q + (1.f - last_alpha) * acc_q;
                 last_q = q;
@@ -238,7 +241,7 @@ GSR_LOAD5(src, cnt * 5);
                 float dmd_dd;
                 const float m_d = gsr_depth_map(c_d, dmd_dd);
                 float dL_dz = w * dL_ddepth;
-                if (cidx == median_contributor - 1) dL_dz += dL_dmedian;
+                if (active && cidx == median_contributor - 1) dL_dz += dL_dmedian;
                 const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
                 dL_dalpha += dL_dweight - last_dL_dT;
                 last_dL_dT = dL_dweight * alpha + one_m_alpha * last_dL_dT;
@@ -256,22 +259,25 @@ GSR_LOAD5(src, cnt * 5);
 
                 const float Twx = a1.z, Twy = a1.w;
                 if (pr.use3d) {
-                    const float dL_dsx = dL_dG * (-G * pr.sx) + dL_dz * Twx;
-                    const float dL_dsy = dL_dG * (-G * pr.sy) + dL_dz * Twy;
-                    const float dpx = dL_dsx * pr.inv_pz, dpy = dL_dsy * pr.inv_pz;
-                    const float dpz = -(dpx * pr.sx + dpy * pr.sy);
-                    // dL/dk = l x dL/dp ; dL/dl = dL/dp x k
-                    const float dkx = pr.ly * dpz - pr.lz * dpy, dky = pr.lz * dpx - pr.lx * dpz, dkz = pr.lx * dpy - pr.ly * dpx;
-                    const float dlx = dpy * pr.kz - dpz * pr.ky, dly = dpz * pr.kx - dpx * pr.kz, dlz = dpx * pr.ky - dpy * pr.kx;
-                    gT[0] = -dkx; gT[1] = -dky; gT[2] = -dkz;
-                    gT[3] = -dlx; gT[4] = -dly; gT[5] = -dlz;
-                    gT[6] = pxf * dkx + pyf * dlx + dL_dz * pr.sx;
-                    gT[7] = pxf * dky + pyf * dly + dL_dz * pr.sy;
-                    gT[8] = pxf * dkz + pyf * dlz + dL_dz;
+                    const float dL_dsx = dL_dG * (-G * sx) + dL_dz * Twx;
+                    const float dL_dsy = dL_dG * (-G * sy) + dL_dz * Twy;
+                    const float dpx = dL_dsx * inv_pz, dpy = dL_dsy * inv_pz;
+                    const float dpz = -(dpx * sx + dpy * sy);
+                    // dL/dTu = -dL/dk = dL/dp x l ;  dL/dTv = -dL/dl = k x dL/dp
+                    const float ux = dpy * pr.lz - dpz * pr.ly, uy = dpz * pr.lx - dpx * pr.lz, uz = dpx * pr.ly - dpy * pr.lx;
+                    const float vx = pr.ky * dpz - pr.kz * dpy, vy = pr.kz * dpx - pr.kx * dpz, vz = pr.kx * dpy - pr.ky * dpx;
+                    gT[0] = ux; gT[1] = uy; gT[2] = uz;
+                    gT[3] = vx; gT[4] = vy; gT[5] = vz;
+                    gT[6] = dL_dz * sx - pxf * ux - pyf * vx;
+                    gT[7] = dL_dz * sy - pxf * uy - pyf * vy;
+                    gT[8] = dL_dz - pxf * uz - pyf * vz;
+                    gxy0 = 0.f; gxy1 = 0.f;
                 } else {
                     gxy0 = dL_dG * (-G * GSR_FILTER_INV_SQUARE * pr.dx);
                     gxy1 = dL_dG * (-G * GSR_FILTER_INV_SQUARE * pr.dy);
-                    if (filter_depth_quirk) { gT[6] = pr.sx * dL_dz; gT[7] = pr.sy * dL_dz; }
+                    gT[0] = 0.f; gT[1] = 0.f; gT[2] = 0.f; gT[3] = 0.f; gT[4] = 0.f; gT[5] = 0.f;
+                    gT[6] = filter_depth_quirk ? sx * dL_dz : 0.f;
+                    gT[7] = filter_depth_quirk ? sy * dL_dz : 0.f;
                     gT[8] = dL_dz;
                 }
             }

@@ -56,19 +56,25 @@ __device__ __forceinline__ float wave_sum2(float a, float b) {
 // ---- 16-lane (one DPP row) reductions: no cross-row traffic at all ------------------------------------
 // Transposed butterfly over the 16 lanes of a row: 8 + 4 + 2 + 1 adds, each fused with its DPP move.
 // On return lane l (0..15 inside its row) holds the ROW total of v[l].
+//
+// Stages "bit 3" and "bit 2" pair lanes that sit in different DPP banks (groups of 4 lanes), so the usual
+// select-then-add (2 v_cndmask + 1 v_add per output) becomes two bank-masked v_add_f32_dpp writing
+// complementary lanes of the same register: dst[lanes of banks M] = src(partner) + src(self).  The compiler has
+// no builtin for a bank-masked fused add, hence the asm; the s_nop of the first stage covers the "VALU write -> DPP read"
+// hazard (2 wait states) that the hazard recogniser cannot see across an asm boundary.
+#define GSR_DPP_PAIR(dst, lo, hi, CTRL, M_LO, M_HI, NOP)                                        \
+    asm volatile(NOP "v_add_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:" M_LO "\n\t"   \
+                 "v_add_f32_dpp %0, %2, %2 " CTRL " row_mask:0xf bank_mask:" M_HI               \
+                 : "=&v"(dst) : "v"(lo), "v"(hi))
 __device__ __forceinline__ float row_sum16_transposed(const float (&v)[16], int l16) {
-    const bool b3 = (l16 & 8) != 0, b2 = (l16 & 4) != 0, b1 = (l16 & 2) != 0, b0 = (l16 & 1) != 0;
+    const bool b1 = (l16 & 2) != 0, b0 = (l16 & 1) != 0;
     float r[8], q[4], p[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {      // bit 3: partner is lane ^ 8 (row_ror:8)
-        const float keep = b3 ? v[i + 8] : v[i], send = b3 ? v[i] : v[i + 8];
-        r[i] = keep + dpp_move<0x128, 0xf>(send);
-    }
+    for (int i = 0; i < 8; ++i)        // bit 3: partner is lane ^ 8 (row_ror:8); lanes 0..7 = banks 0,1 keep v[i]
+        GSR_DPP_PAIR(r[i], v[i], v[i + 8], "row_ror:8", "0x3", "0xc", "s_nop 1\n\t");
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {      // bit 2: partner is lane ^ 7 (row_half_mirror); it keeps the other half
-        const float keep = b2 ? r[i + 4] : r[i], send = b2 ? r[i] : r[i + 4];
-        q[i] = keep + dpp_move<0x141, 0xf>(send);
-    }
+    for (int i = 0; i < 4; ++i)        // bit 2: partner is lane ^ 7 (row_half_mirror); banks 0,2 keep r[i]
+        GSR_DPP_PAIR(q[i], r[i], r[i + 4], "row_half_mirror", "0x5", "0xa", "");   // inputs written >= 6 instructions ago
 #pragma unroll
     for (int i = 0; i < 2; ++i) {      // bit 1: partner is lane ^ 2 (quad_perm [2,3,0,1])
         const float keep = b1 ? q[i + 2] : q[i], send = b1 ? q[i] : q[i + 2];
