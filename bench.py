@@ -61,6 +61,19 @@ def iteration_bytes(N, D, P, tiles):
     return sum(b.values()) + D * 12 * (1 + 2 * npass) + N * 58 * 28
 
 
+def pmc_traffic_bytes(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (collected in separate rocprofv3 --pmc
+    passes; counters cannot be read inside this process).  gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE
+    counts half of the bytes of wide coalesced reads.  None when the summary does not cover the kernel."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"].get(kernel)
+        return int((2.0 * k["fetch_kb"] + k["write_kb"]) * 1024) if k else None
+    except (OSError, KeyError, TypeError, ValueError):
+        return None
+
+
 def cpu_baseline(params, cam, n_tiles_sample, n_gauss_sample, dbg, W, H):
     """Oracle (pure PyTorch, fp32) on the host cores: preprocess on a sample of the Gaussians,
     forward+backward compositing on a sample of the frame's tiles (the frame's own tile lists),
@@ -217,7 +230,9 @@ def main():
                        "gaussians": N, "width": W, "height": H, "instances_D": D,
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(dom),
+                         "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, same scene; "
+                                           "2 x FETCH_SIZE + WRITE_SIZE)",
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per_kernel[dom]},
             "kernel_ms": {k: round(v, 4) for k, v in per_kernel.items()},
             "kernel_ms_per_step": {k: round(ms / args.steps, 4) for k, (ms, n) in prof.items() if n},
