@@ -132,6 +132,18 @@ static int validate(const GsrView* v, const GsrGaussians* g) {
     return GSR_OK;
 }
 
+// 4 bytes of pinned host memory per calling thread, for the one device -> host read of gsr_forward; allocated on
+// first use and kept (a forward is synchronous with respect to this read, so one slot per thread suffices).
+static uint32_t* pinned_counter() {
+    thread_local uint32_t* slot = nullptr;
+    if (!slot) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) return nullptr;
+        slot = static_cast<uint32_t*>(p);
+    }
+    return slot;
+}
+
 static inline int bits_for(uint32_t n_values) {   // bits needed to represent 0..n_values-1
     int b = 0;
     while ((1ull << b) < n_values) ++b;
@@ -203,14 +215,19 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         // The instance count sizes the next buffers, so the host has to see it: the copy is followed by
         // an event, and the SH colour pass is enqueued BEHIND that event so that it runs during the
         // host round trip (wait on the event, allocate, launch) instead of leaving the GPU idle.
+        // The destination must be PINNED: a copy into pageable memory blocks the host inside hipMemcpyAsync
+        // until the data has arrived, the colour pass is then launched late and the GPU idles ~40 us.
+        uint32_t* d_host = pinned_counter();
+        if (!d_host) { gsr_set_error("hipHostMalloc failed (instance-count read-back buffer)"); return GSR_E_HIP; }
         hipEvent_t ev;
         GSR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        hipError_t e1 = hipMemcpyAsync(&D, offs + N, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        hipError_t e1 = hipMemcpyAsync(d_host, offs + N, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         hipError_t e2 = e1 == hipSuccess ? hipEventRecord(ev, s) : e1;
         rc = e2 == hipSuccess ? gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, s) : GSR_OK;
         hipError_t e3 = e2 == hipSuccess ? hipEventSynchronize(ev) : e2;   // the one host wait of the forward
         (void)hipEventDestroy(ev);
         GSR_HIP_CHECK(e3);
+        D = *d_host;
         if (rc != GSR_OK) return rc;
     }
     if (D > 0x7FFFFFF0u) { gsr_set_error("instance count %u overflows", D); return GSR_E_UNSUPPORTED; }
