@@ -384,27 +384,18 @@ int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const 
     return GSR_OK;
 }
 
-// Per sorted instance: Gaussian id, emission index, tile ranges, and the splat record copied into
-// (tile, depth) order.  5 threads per instance, one 16-byte piece each; piece 0 also does the
-// bookkeeping.
-__global__ void __launch_bounds__(256) finalize_bins_kernel(long long n_pieces, int D,
-                                                            const uint32_t* __restrict__ tile_sorted,
+// Per sorted instance: Gaussian id, emission index and the tile ranges.  (The 80-byte records themselves are
+// NOT copied into list order any more: the render kernels gather them by id, see render_fwd.hip.)
+__global__ void __launch_bounds__(256) finalize_bins_kernel(int D, const uint32_t* __restrict__ tile_sorted,
                                                             const uint32_t* __restrict__ perm,
                                                             const uint32_t* __restrict__ emit_gid,
-                                                            const float4* __restrict__ splat,
                                                             uint32_t* __restrict__ point_list,
                                                             uint32_t* __restrict__ inst_row,
-                                                            uint32_t* __restrict__ ranges,
-                                                            float4* __restrict__ stream) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_pieces) return;
-    const int i = (int)(idx / 5);
-    const int q = (int)(idx - (long long)i * 5);
+                                                            uint32_t* __restrict__ ranges) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
     const uint32_t e = perm[i];
-    const uint32_t gid = emit_gid[e];
-    stream[idx] = splat[(size_t)gid * 5 + q];
-    if (q != 0) return;
-    point_list[i] = gid;
+    point_list[i] = emit_gid[e];
     inst_row[i] = e;
     const uint32_t t = tile_sorted[i];
     if (i == 0) ranges[2 * t] = 0;
@@ -416,15 +407,13 @@ __global__ void __launch_bounds__(256) finalize_bins_kernel(long long n_pieces, 
 }
 
 int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted, const uint32_t* perm,
-                             const uint32_t* emit_gid, const float* splat, uint32_t* point_list,
-                             uint32_t* inst_row, uint32_t* ranges, float* stream, hipStream_t s) {
+                             const uint32_t* emit_gid, uint32_t* point_list, uint32_t* inst_row, uint32_t* ranges,
+                             hipStream_t s) {
     GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
     if (D <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_FINALIZE, s);
-    const long long n_pieces = (long long)D * 5;
-    hipLaunchKernelGGL(finalize_bins_kernel, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, s, n_pieces, D,
-                       tile_keys_sorted, perm, emit_gid, reinterpret_cast<const float4*>(splat), point_list,
-                       inst_row, ranges, reinterpret_cast<float4*>(stream));
+    hipLaunchKernelGGL(finalize_bins_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, D,
+                       tile_keys_sorted, perm, emit_gid, point_list, inst_row, ranges);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

@@ -260,14 +260,13 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         rc = gsr_radix_sort_pairs(tile_keys, inst_vals, tile_sorted, perm, tk_tmp, tv_tmp, D, 0,
                                   bits_for((uint32_t)n_tiles), sort_ws2, s);
         if (rc != GSR_OK) return rc;
-        rc = gsr_launch_finalize_bins((int)D, n_tiles, tile_sorted, perm, emit_gid, splat, point_list, inst_row, ranges,
-                                      at<float>(binning, BL.stream), s);
+        rc = gsr_launch_finalize_bins((int)D, n_tiles, tile_sorted, perm, emit_gid, point_list, inst_row, ranges, s);
         if (rc != GSR_OK) return rc;
     } else {
         GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
     }
 
-    return gsr_launch_render_fwd(*view, ranges, at<float>(binning, BL.stream), at<float>(image, IL.final_T),
+    return gsr_launch_render_fwd(*view, ranges, splat, at<float>(image, IL.final_T),
                                  at<uint32_t>(image, IL.n_contrib), out->out_color, out->out_allmap,
                                  at<uint8_t>(binning, BL.touch), view->channels == 3 ? nullptr : g->colors_precomp,
                                  point_list, s);
@@ -324,7 +323,7 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
         rc = gsr_exclusive_scan_u32(slot_cnt, nullptr, slot_off, num_rendered, scan_ws, s);
         if (rc != GSR_OK) return rc;
         rc = gsr_launch_render_bwd(*view, at<uint32_t>(binning, BL.ranges), at<uint32_t>(binning, BL.inst_row),
-                                   at<float>(binning, BL.stream), touch, slot_off, at<float>(image, IL.final_T),
+                                   at<float>(geom, GL.splat), touch, slot_off, at<float>(image, IL.final_T),
                                    at<uint32_t>(image, IL.n_contrib), dL_dcolor, dL_dallmap, grad_rows,
                                    wide ? g->colors_precomp : nullptr, at<uint32_t>(binning, BL.point_list), feat_rows, s);
         if (rc != GSR_OK) return rc;
@@ -373,7 +372,6 @@ extern "C" int32_t gsr_buffer_field(int32_t which, const char* name, int32_t N, 
         if (!strcmp(name, "point_list")) { *offset = L.point_list; *bytes = size_t(D) * 4; return GSR_OK; }
         if (!strcmp(name, "inst_row")) { *offset = L.inst_row; *bytes = size_t(D) * 4; return GSR_OK; }
         if (!strcmp(name, "ranges")) { *offset = L.ranges; *bytes = size_t(gx) * gy * 8; return GSR_OK; }
-        if (!strcmp(name, "stream")) { *offset = L.stream; *bytes = size_t(D) * GSR_SPLAT_FLOATS * 4; return GSR_OK; }
     } else if (which == GSR_BUF_IMAGE) {
         const GsrImageLayout L(P);
         if (!strcmp(name, "final_T")) { *offset = L.final_T; *bytes = size_t(P) * 12; return GSR_OK; }

@@ -78,15 +78,12 @@ struct GsrGeomLayout {
     }
 };
 struct GsrBinLayout {
-    size_t point_list, inst_row, ranges, stream, touch, total;
+    size_t point_list, inst_row, ranges, touch, total;
     GsrBinLayout(int64_t D, int64_t tiles) {
         size_t o = 0;
         point_list = o; o += gsr_align(size_t(D) * 4);
         inst_row = o;   o += gsr_align(size_t(D) * 4);
         ranges = o;     o += gsr_align(size_t(tiles) * 8);
-        // splat records copied into (tile, depth) order: the render kernels stream them with
-        // coalesced loads instead of gathering 80-byte records by Gaussian id twice per iteration
-        stream = o;     o += gsr_align(size_t(D) * GSR_SPLAT_FLOATS * 4);
         // one byte per (sorted instance, quad): did the forward blend it into >= 1 pixel of that quad?
         // The backward evaluates exactly those pairs (everything else has zero gradient).
         touch = o;      o += gsr_align(size_t(D) * 4);
@@ -126,16 +123,15 @@ int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const 
                     const uint2* rank_rect, uint32_t* tile_keys, uint32_t* inst_vals,
                     uint32_t* emit_gid, hipStream_t s);
 int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted,
-                             const uint32_t* perm, const uint32_t* emit_gid, const float* splat,
-                             uint32_t* point_list, uint32_t* inst_row, uint32_t* ranges,
-                             float* stream, hipStream_t s);
-int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* stream,
+                             const uint32_t* perm, const uint32_t* emit_gid,
+                             uint32_t* point_list, uint32_t* inst_row, uint32_t* ranges, hipStream_t s);
+int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* splat,
                           float* final_T, uint32_t* n_contrib, float* out_color,
                           float* out_allmap, uint8_t* touch, const float* feat, const uint32_t* point_list,
                           hipStream_t s);
 int gsr_launch_slot_count(int D, const uint32_t* touch, const uint32_t* inst_row, uint32_t* cnt, hipStream_t s);
 int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* inst_row,
-                          const float* stream, const uint32_t* touch, const uint32_t* slot_off, const float* final_T,
+                          const float* splat, const uint32_t* touch, const uint32_t* slot_off, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
                           const float* feat, const uint32_t* point_list, float* feat_rows, hipStream_t s);
 int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint32_t* offs, const uint32_t* slot_off,

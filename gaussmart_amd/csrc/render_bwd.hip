@@ -8,8 +8,8 @@
 // a tile's workgroup owns an 8x8 pixel quad and never synchronises with the other three; each DPP row of
 // 16 lanes owns one 4x4 pixel block of that quad and walks ITS OWN list:
 //   * the wave starts at the deepest list entry ANY OF ITS 64 PIXELS reached (quad-level, not tile-level)
-//     and streams the (tile, depth)-ordered splat records backwards, 64 per batch, coalesced, into
-//     its private LDS slice while the next batch is prefetched into registers;
+//     and walks the (tile, depth)-ordered list backwards, 64 entries per batch: ids two batches ahead,
+//     the 80-byte records gathered by id one batch ahead into registers, then into its private LDS slice;
 //   * the forward left 4 bits per (instance, quad): "blended into >= 1 pixel of block g".  Four ballots
 //     turn them into one 64-bit to-do mask PER BLOCK; every iteration each row takes the deepest entry
 //     of its own mask, so the wave needs max_g |list_g| iterations instead of |union of the lists|
@@ -25,17 +25,22 @@
 #include "pair_eval.h"
 #include "wave_reduce.h"
 
-// five coalesced 16-byte loads per lane = 64 records of 80 bytes; pieces beyond `lim` read as zero
-#define GSR_LOAD5(ptr, lim)                                            \
-    do {                                                               \
-        const int lim_ = (lim);                                        \
-        pf0 = zero4; pf1 = zero4; pf2 = zero4; pf3 = zero4; pf4 = zero4; \
-        if (lane < lim_) pf0 = (ptr)[lane];                            \
-        if (64 + lane < lim_) pf1 = (ptr)[64 + lane];                  \
-        if (128 + lane < lim_) pf2 = (ptr)[128 + lane];                \
-        if (192 + lane < lim_) pf3 = (ptr)[192 + lane];                \
-        if (256 + lane < lim_) pf4 = (ptr)[256 + lane];                \
+// Records are gathered by Gaussian id straight from the splat table (80-byte records, 16-byte aligned): lane l
+// fetches the five 16-byte parts of staged entry l, whose id it already holds.  (A cooperative mapping --
+// consecutive lanes = consecutive parts -- touches fewer lines per instruction but needs five ds_bpermute and ten
+// more live registers; measured slower.)  No copy of the records in list order exists any more: the former
+// "splat stream" cost a 140 us kernel and 240 MB per frame to save the render kernels nothing they can feel.
+#define GSR_GATHER5(ids_, cnt_)                                                                      \
+    do {                                                                                             \
+        pf0 = zero4; pf1 = zero4; pf2 = zero4; pf3 = zero4; pf4 = zero4;                             \
+        if (lane < (cnt_)) {                                                                         \
+            const float4* rec_ = p.splat + (size_t)(ids_) * 5;                                       \
+            pf0 = rec_[0]; pf1 = rec_[1]; pf2 = rec_[2]; pf3 = rec_[3]; pf4 = rec_[4];               \
+        }                                                                                            \
     } while (0)
+
+#define RF_BLOCK 256
+#define RF_WAVES 4
 
 #define RB_BLOCK 256
 #define RB_WAVES 4
@@ -45,7 +50,7 @@ struct RenderBwdParams {
     int W, H, gx;
     uint32_t flags;
     const uint32_t* ranges; const uint32_t* inst_row;
-    const float4* stream; const uint32_t* touch; const uint32_t* slot_off; const float* bg;
+    const float4* splat; const uint32_t* touch; const uint32_t* slot_off; const float* bg;
     const float* final_T; const uint32_t* n_contrib;
     const float* dL_dcolor; const float* dL_dallmap;
     float* grad_rows;
@@ -135,32 +140,35 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
     float4 pf0, pf1, pf2, pf3, pf4;
     uint32_t pf_touch = 0;   // named (not an array): keeps the prefetch in VGPRs, not scratch
     uint32_t pf_row = 0;
-    uint32_t pf_id = 0;
     int hi = max_contrib;
+    // ids run two batches ahead of the replay, records (and the per-entry words) one batch ahead
+    uint32_t ids_cur, ids_nxt;
     {
         const int lo = max(0, hi - 64), cnt = hi - lo;
-        const float4* src = p.stream + (size_t)(r0 + lo) * 5;
-GSR_LOAD5(src, cnt * 5);
+        ids_cur = lane < cnt ? p.point_list[r0 + lo + lane] : 0u;
+        GSR_GATHER5(ids_cur, cnt);
         pf_row = lane < cnt ? p.inst_row[r0 + lo + lane] : 0u;
         pf_touch = lane < cnt ? p.touch[(size_t)r0 + lo + lane] : 0u;
-        if (FEAT16 > 0) pf_id = lane < cnt ? p.point_list[r0 + lo + lane] : 0u;
+        const int lo2 = max(0, lo - 64), cnt2 = lo - lo2;
+        ids_nxt = lane < cnt2 ? p.point_list[r0 + lo2 + lane] : 0u;
     }
 
     while (hi > 0) {
         const int lo = max(0, hi - 64), nb = hi - lo;
-s_rec[lane] = pf0; s_rec[64 + lane] = pf1; s_rec[128 + lane] = pf2; s_rec[192 + lane] = pf3; s_rec[256 + lane] = pf4;
+s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_rec[lane * 5 + 3] = pf3; s_rec[lane * 5 + 4] = pf4;
         const uint32_t row_of_lane = pf_row;          // emission index of staged entry `lane`
         const uint32_t touch_of_lane = pf_touch;      // 4 bytes (one per quad) x 4 bits (one per 4x4 block): blended there?
         // first gradient row of staged entry `lane` (its rows are dense, in (quad, block) order of the set bits)
         const uint32_t slot_of_lane = lane < nb ? p.slot_off[row_of_lane] : 0u;
-        const uint32_t id_of_lane = pf_id;            // Gaussian id of staged entry `lane` (wide payload only)
+        const uint32_t id_of_lane = ids_cur;          // Gaussian id of staged entry `lane` (wide payload only)
         {   // prefetch the next (shallower) batch
             const int hi2 = lo, lo2 = max(0, hi2 - 64), cnt = hi2 - lo2;
-            const float4* src = p.stream + (size_t)(r0 + lo2) * 5;
-GSR_LOAD5(src, cnt * 5);
+            GSR_GATHER5(ids_nxt, cnt);
             pf_row = lane < cnt ? p.inst_row[r0 + lo2 + lane] : 0u;
             pf_touch = lane < cnt ? p.touch[(size_t)r0 + lo2 + lane] : 0u;
-            if (FEAT16 > 0) pf_id = lane < cnt ? p.point_list[r0 + lo2 + lane] : 0u;
+            ids_cur = ids_nxt;
+            const int lo3 = max(0, lo2 - 64), cnt3 = lo2 - lo3;
+            ids_nxt = lane < cnt3 ? p.point_list[r0 + lo3 + lane] : 0u;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -369,14 +377,14 @@ int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint3
 }
 
 int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* inst_row,
-                          const float* stream, const uint32_t* touch, const uint32_t* slot_off, const float* final_T,
+                          const float* splat, const uint32_t* touch, const uint32_t* slot_off, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
                           const float* feat, const uint32_t* point_list, float* feat_rows, hipStream_t s) {
     RenderBwdParams p;
     p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
     p.flags = v.flags;
-    p.ranges = ranges; p.inst_row = inst_row; p.stream = reinterpret_cast<const float4*>(stream); p.touch = touch;
+    p.ranges = ranges; p.inst_row = inst_row; p.splat = reinterpret_cast<const float4*>(splat); p.touch = touch;
     p.slot_off = slot_off; p.bg = v.bg;
     p.final_T = final_T; p.n_contrib = n_contrib; p.dL_dcolor = dL_dcolor; p.dL_dallmap = dL_dallmap;
     p.grad_rows = grad_rows;

@@ -5,9 +5,10 @@
 // MI355X mapping: WAVE-INDEPENDENT.  A 16x16 tile is still one 256-thread workgroup (tile keys stay
 // those of the reference), but its four wave64s each own an 8x8 pixel quad and never synchronise
 // with each other -- no workgroup barrier anywhere:
-//   * a wave streams the tile's splat records (already in (tile, depth) order, see binning.hip)
-//     64 at a time with five coalesced 16-byte loads per lane into its PRIVATE 5 KiB LDS slice, the
-//     next 64 being prefetched into registers while the current ones are composited;
+//   * a wave stages the tile's splat records 64 at a time into its PRIVATE 5 KiB LDS slice: the Gaussian
+//     ids of the list (point_list) are read two batches ahead, the 80-byte records are gathered by id
+//     one batch ahead (five 16-byte loads per lane, consecutive lanes = consecutive pieces of a record)
+//     into registers while the current batch is composited -- no copy of the records in list order;
 //   * each lane tests ONE staged splat's cull rect against the wave's quad; the 64-bit ballot is the
 //     list of splats the wave has to look at at all (iterated with s_ff1), the rest cost nothing;
 //   * per surviving splat the record is read with wave-uniform (broadcast) ds_read_b128;
@@ -17,16 +18,18 @@
 #include "gsr_common.h"
 #include "pair_eval.h"
 
-// five coalesced 16-byte loads per lane = 64 records of 80 bytes; pieces beyond `lim` read as zero
-#define GSR_LOAD5(ptr, lim)                                            \
-    do {                                                               \
-        const int lim_ = (lim);                                        \
-        pf0 = zero4; pf1 = zero4; pf2 = zero4; pf3 = zero4; pf4 = zero4; \
-        if (lane < lim_) pf0 = (ptr)[lane];                            \
-        if (64 + lane < lim_) pf1 = (ptr)[64 + lane];                  \
-        if (128 + lane < lim_) pf2 = (ptr)[128 + lane];                \
-        if (192 + lane < lim_) pf3 = (ptr)[192 + lane];                \
-        if (256 + lane < lim_) pf4 = (ptr)[256 + lane];                \
+// Records are gathered by Gaussian id straight from the splat table (80-byte records, 16-byte aligned): lane l
+// fetches the five 16-byte parts of staged entry l, whose id it already holds.  (A cooperative mapping --
+// consecutive lanes = consecutive parts -- touches fewer lines per instruction but needs five ds_bpermute and ten
+// more live registers; measured slower.)  No copy of the records in list order exists any more: the former
+// "splat stream" cost a 140 us kernel and 240 MB per frame to save the render kernels nothing they can feel.
+#define GSR_GATHER5(ids_, cnt_)                                                                      \
+    do {                                                                                             \
+        pf0 = zero4; pf1 = zero4; pf2 = zero4; pf3 = zero4; pf4 = zero4;                             \
+        if (lane < (cnt_)) {                                                                         \
+            const float4* rec_ = p.splat + (size_t)(ids_) * 5;                                       \
+            pf0 = rec_[0]; pf1 = rec_[1]; pf2 = rec_[2]; pf3 = rec_[3]; pf4 = rec_[4];               \
+        }                                                                                            \
     } while (0)
 
 #define RF_BLOCK 256
@@ -35,7 +38,7 @@
 struct RenderFwdParams {
     int W, H, gx;
     uint32_t flags;
-    const uint32_t* ranges; const float4* stream;
+    const uint32_t* ranges; const float4* splat;   // splat table [N] x 5 float4, gathered by id
     const float* bg;
     float* final_T; uint32_t* n_contrib; float* out_color; float* out_allmap;
     uint8_t* touch;
@@ -84,33 +87,29 @@ __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : 2) rend
     float Cf[NF];
 #pragma unroll
     for (int k = 0; k < NF; ++k) Cf[k] = 0.f;
-    uint32_t pf_id = 0;
     float N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float Dacc = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med_depth = 0.f;
     uint32_t med_contrib = 0xFFFFFFFFu;   // "-1" stored in the u32 plane, as recalled
 
-    // records of one batch are 64*5 consecutive float4: lane l fetches pieces l, l+64, ... (coalesced)
-    const float4* src = p.stream + (size_t)r0 * 5;
     float4 pf0, pf1, pf2, pf3, pf4;   // named (not an array): keeps the prefetch in VGPRs, not scratch
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    {
-        const int lim = min(64, n_list) * 5;
-GSR_LOAD5(src, lim);
-        if (FEAT16 > 0 && lane < min(64, n_list)) pf_id = p.point_list[r0 + lane];
-    }
+    // ids run two batches ahead of the compositing, records one batch ahead
+    uint32_t ids_cur = lane < min(64, n_list) ? p.point_list[r0 + lane] : 0u;
+    GSR_GATHER5(ids_cur, min(64, n_list));
+    uint32_t ids_nxt = 64 + lane < n_list ? p.point_list[r0 + 64 + lane] : 0u;
 
     int covered = 0;   // list entries whose touch byte this wave has written
     for (int base = 0; base < n_list; base += 64) {
         if (__all(done)) break;
         const int nb = min(64, n_list - base);
-s_rec[lane] = pf0; s_rec[64 + lane] = pf1; s_rec[128 + lane] = pf2; s_rec[192 + lane] = pf3; s_rec[256 + lane] = pf4;
-        const uint32_t id_of_lane = pf_id;
+s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_rec[lane * 5 + 3] = pf3; s_rec[lane * 5 + 4] = pf4;
+        const uint32_t id_of_lane = ids_cur;
         {   // prefetch the next batch while this one is composited
             const int nxt = base + 64;
-            const int lim = nxt < n_list ? min(64, n_list - nxt) * 5 : 0;
-            const float4* s2 = src + (size_t)nxt * 5;
-GSR_LOAD5(s2, lim);
-            if (FEAT16 > 0 && nxt < n_list && lane < min(64, n_list - nxt)) pf_id = p.point_list[r0 + nxt + lane];
+            const int cnt_nxt = nxt < n_list ? min(64, n_list - nxt) : 0;
+            GSR_GATHER5(ids_nxt, cnt_nxt);
+            ids_cur = ids_nxt;
+            ids_nxt = nxt + 64 + lane < n_list ? p.point_list[r0 + nxt + 64 + lane] : 0u;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -214,14 +213,14 @@ GSR_LOAD5(s2, lim);
     }
 }
 
-int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* stream,
+int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* splat,
                           float* final_T, uint32_t* n_contrib, float* out_color,
                           float* out_allmap, uint8_t* touch, const float* feat, const uint32_t* point_list,
                           hipStream_t s) {
     RenderFwdParams p;
     p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE; p.flags = v.flags;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
-    p.ranges = ranges; p.stream = reinterpret_cast<const float4*>(stream); p.bg = v.bg;
+    p.ranges = ranges; p.splat = reinterpret_cast<const float4*>(splat); p.bg = v.bg;
     p.final_T = final_T; p.n_contrib = n_contrib; p.out_color = out_color; p.out_allmap = out_allmap;
     p.touch = touch; p.feat = feat; p.point_list = point_list; p.C = v.channels;
     if (p.gx <= 0 || gy <= 0) return GSR_OK;
