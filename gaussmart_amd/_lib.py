@@ -23,6 +23,7 @@ GSR_FLAG_FILTER_DEPTH_GRAD = 2
 GSR_FLAGS_UPSTREAM = 3
 GSR_FLAG_DEBUG_NO_CULL = 4
 GSR_FLAG_RAW_PARAMS = 8
+GSR_FLAG_COLOR_AFTER_ALLOC = 16
 
 KERNEL_NAMES = ("preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
                 "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "loss_fwd", "loss_bwd",

@@ -201,6 +201,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     void* sort_ws = scratch + 4 * nb;
     void* scan_ws = static_cast<char*>(sort_ws) + sort_ws_n;
 
+    const bool color_after_alloc = (view->flags & (uint32_t)GSR_FLAG_COLOR_AFTER_ALLOC) != 0;
     uint32_t D = 0;
     if (N > 0) {
         rc = gsr_launch_preprocess_fwd(*view, *g, splat, clamped, tiles_touched, tile_rect, depth_key, out->radii, s);
@@ -223,7 +224,8 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         GSR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         hipError_t e1 = hipMemcpyAsync(d_host, offs + N, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         hipError_t e2 = e1 == hipSuccess ? hipEventRecord(ev, s) : e1;
-        rc = e2 == hipSuccess ? gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, s) : GSR_OK;
+        if (!color_after_alloc)
+            rc = e2 == hipSuccess ? gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, s) : GSR_OK;
         hipError_t e3 = e2 == hipSuccess ? hipEventSynchronize(ev) : e2;   // the one host wait of the forward
         (void)hipEventDestroy(ev);
         GSR_HIP_CHECK(e3);
@@ -236,6 +238,10 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     const GsrBinLayout BL(D, n_tiles);
     void* binning = alloc(ctx, GSR_BUF_BINNING, BL.total);
     if (!binning) { gsr_set_error("allocator returned NULL (binning)"); return GSR_E_ALLOC; }
+    if (color_after_alloc && N > 0) {   // the caller may have enqueued a stream wait inside the callback above
+        rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, s);
+        if (rc != GSR_OK) return rc;
+    }
     out->binning = binning;
     uint32_t* point_list = at<uint32_t>(binning, BL.point_list);
     uint32_t* inst_row = at<uint32_t>(binning, BL.inst_row);

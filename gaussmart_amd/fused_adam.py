@@ -17,7 +17,11 @@ class FusedAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, only=None, stream=None):
+        """`only`: iterable of parameters to update (the others keep their state and step count untouched);
+        `stream`: torch.cuda.Stream to launch on instead of the current one.  Both serve the pipelined
+        data-parallel step, which updates the geometry tensors and the SH tensors at different times."""
+        only_ids = None if only is None else {id(p) for p in only}
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -27,7 +31,7 @@ class FusedAdam(torch.optim.Adam):
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or (only_ids is not None and id(p) not in only_ids):
                     continue
                 if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous():
                     raise _lib.GsrError("FusedAdam needs contiguous float32 parameters on a HIP device")
@@ -44,7 +48,7 @@ class FusedAdam(torch.optim.Adam):
                     (p, g, st["exp_avg"], st["exp_avg_sq"], group["lr"] / (1.0 - beta1 ** t), 1.0 / math.sqrt(1.0 - beta2 ** t)))
         for (dev, beta1, beta2, eps), items in batches.items():
             with torch.cuda.device(dev):
-                stream = torch.cuda.current_stream(dev).cuda_stream
+                stream_h = (stream if stream is not None else torch.cuda.current_stream(dev)).cuda_stream
                 for i in range(0, len(items), self.MAX_TENSORS):
                     chunk = items[i:i + self.MAX_TENSORS]
                     n = len(chunk)
@@ -52,5 +56,5 @@ class FusedAdam(torch.optim.Adam):
                     _lib.check(L.gsr_adam_step(
                         n, arr(0), arr(1), arr(2), arr(3), (C.c_int64 * n)(*[c[0].numel() for c in chunk]),
                         (C.c_float * n)(*[c[4] for c in chunk]), (C.c_float * n)(*[c[5] for c in chunk]),
-                        beta1, beta2, eps, C.c_void_p(stream)))
+                        beta1, beta2, eps, C.c_void_p(stream_h)))
         return loss

@@ -131,10 +131,11 @@ class _Lease:
 class _Allocator:
     """Adapter between gsr_alloc_fn and the pool for ONE library call."""
 
-    def __init__(self, device):
+    def __init__(self, device, before_binning=None):
         self.device = device
         self.buffers = {}
         self.error = None
+        self.before_binning = before_binning    # called once, right before the BINNING buffer is handed out
         self.stream = torch.cuda.current_stream(device).cuda_stream
         self.kept = _Lease()        # geom / binning / image: travel with the autograd node
         self.scratch = _Lease()     # released by done()
@@ -143,6 +144,9 @@ class _Allocator:
     def _alloc(self, _ctx, which, nbytes):
         try:
             which, nbytes = int(which), max(int(nbytes), 1)
+            if which == _lib.GSR_BUF_BINNING and self.before_binning is not None:
+                hook, self.before_binning = self.before_binning, None
+                hook()
             key = (self.device, self.stream, which)
             t = _POOL.take(key, nbytes, self.device)
             lease = self.scratch if which in (_lib.GSR_BUF_SCRATCH, _lib.GSR_BUF_SCRATCH2) else self.kept
@@ -175,6 +179,24 @@ def _finish_lease(ctx):
     # retain_grad hooks are only broken by the cyclic GC), so the lease is returned here
     if not KEEP_BUFFERS_AFTER_BACKWARD:
         ctx.lease.release()
+
+
+# Pipelined data-parallel step (view_parallel.py): the SH parameters may still be receiving their Adam update on a
+# side stream when the next forward starts.  The event that marks the end of that update is parked here; the raw
+# forward lets its geometry / binning phase run and makes the stream wait right before the SH colour pass
+# (GSR_FLAG_COLOR_AFTER_ALLOC); every other consumer waits up front.
+_PENDING_PARAM_EVENT = {}
+
+
+def set_pending_param_event(device, event):
+    _PENDING_PARAM_EVENT[torch.device(device)] = event
+
+
+def wait_pending_params(device):
+    """Make the current stream wait for an outstanding side-stream parameter update (no-op if there is none)."""
+    ev = _PENDING_PARAM_EVENT.pop(torch.device(device), None)
+    if ev is not None:
+        torch.cuda.current_stream(device).wait_event(ev)
 
 
 def release_workspace():
@@ -210,6 +232,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if device.type != "cuda":
             raise _lib.GsrError("GaussianRasterizer needs tensors on a HIP device (torch 'cuda'); "
                                 "there is no CPU path")
+        wait_pending_params(device)
         rs = raster_settings
         N = means3D.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
@@ -336,6 +359,11 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             raise ValueError("features_dc must be [N,1,3] and features_rest [N,K-1,3]")
         M = 1 + f_rest.shape[1]
         flags = int(flags) | _lib.GSR_FLAG_RAW_PARAMS
+        pending = _PENDING_PARAM_EVENT.pop(torch.device(device), None)
+        hook = None
+        if pending is not None:
+            flags |= _lib.GSR_FLAG_COLOR_AFTER_ALLOC
+            hook = lambda: torch.cuda.current_stream(device).wait_event(pending)
         rest = f_rest if f_rest.shape[1] > 0 else None
         with torch.cuda.device(device):
             view, keep = _make_view(rs, M, flags, device)
@@ -345,15 +373,17 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             allmap = torch.empty((7, H, W), dtype=torch.float32, device=device)
             radii = torch.empty((N,), dtype=torch.int32, device=device)
             out = _lib.GsrForwardOut(color.data_ptr(), allmap.data_ptr(), radii.data_ptr(), 0, None, None, None)
-            alloc = _Allocator(device)
+            alloc = _Allocator(device, before_binning=hook)
             stream = torch.cuda.current_stream(device).cuda_stream
             rc = L.gsr_forward(C.byref(view), C.byref(g), C.byref(out), alloc.cb, None, C.c_void_p(stream))
             alloc.done()
+            if alloc.before_binning is not None:     # the library returned before asking for the binning buffer
+                alloc.before_binning()
             if rc != 0 and alloc.error is not None:
                 raise alloc.error
             _lib.check(rc)
         ctx.lease = alloc.kept
-        ctx.raster_settings, ctx.flags, ctx.num_rendered, ctx.M = rs, flags, int(out.num_rendered), M
+        ctx.raster_settings, ctx.flags, ctx.num_rendered, ctx.M = rs, flags & ~_lib.GSR_FLAG_COLOR_AFTER_ALLOC, int(out.num_rendered), M
         ctx.view_keep = keep
         ctx.set_materialize_grads(False)     # no zero tensors for the unused radii / image gradients
         ctx.save_for_backward(xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, radii,
@@ -379,9 +409,16 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             view, keep = _make_view(rs, ctx.M, ctx.flags, device, 3, ctx.view_keep)
             g = _lib.GsrGaussians(N, _ptr(xyz), _ptr(f_dc), None, _ptr(opacity_raw), _ptr(scaling_raw),
                                   _ptr(rotation_raw), None, _ptr(rest) if rest is not None else None)
-            d_xyz, d_2d = torch.empty_like(xyz), torch.empty((N, 3), dtype=torch.float32, device=device)
-            d_dc, d_rest = torch.empty_like(f_dc), torch.empty_like(f_rest)
-            d_op, d_sc, d_rot = torch.empty_like(opacity_raw), torch.empty_like(scaling_raw), torch.empty_like(rotation_raw)
+            # ONE buffer for the six parameter gradients, [xyz | f_dc | opacity | scaling | rotation | f_rest]: the
+            # data-parallel step all-reduces it as a whole (or as "geometry + dc" / "rest" halves) without copies
+            d_2d = torch.empty((N, 3), dtype=torch.float32, device=device)
+            srcs = (xyz, f_dc, opacity_raw, scaling_raw, rotation_raw, f_rest)
+            offs, total = [], 0
+            for t in srcs:                       # every segment starts 16-byte aligned (K8 stores float4)
+                offs.append(total)
+                total += _round_up(t.numel(), 4)
+            flat = torch.empty(total, dtype=torch.float32, device=device)
+            d_xyz, d_dc, d_op, d_sc, d_rot, d_rest = [flat[o:o + t.numel()].view_as(t) for o, t in zip(offs, srcs)]
             grads = _lib.GsrGrads(_ptr(d_xyz), _ptr(d_2d), _ptr(d_op), _ptr(d_dc), None, _ptr(d_sc), _ptr(d_rot), None,
                                   _ptr(d_rest) if rest is not None else None)
             alloc = _Allocator(device)

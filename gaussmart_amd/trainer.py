@@ -69,11 +69,15 @@ def training_step(gaussians, viewpoint_cam, gt_image, opt, pipe, background, ite
     render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=not on_device)
     total, parts = training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam, pipe)
     total.backward(gradient=_unit_gradient(total))   # cached: saves the ones_like() fill of every step
-    if view_parallel is not None:
-        view_parallel.allreduce_gradients()
-    if step_optimizer:
-        gaussians.optimizer.step()
+    if view_parallel is not None and step_optimizer:
+        view_parallel.reduce_and_step(gaussians.optimizer)      # pipelined when RCCL + fused kernels allow it
         gaussians.optimizer.zero_grad(set_to_none=True)
+    else:
+        if view_parallel is not None:
+            view_parallel.allreduce_gradients()
+        if step_optimizer:
+            gaussians.optimizer.step()
+            gaussians.optimizer.zero_grad(set_to_none=True)
     parts["total"] = total.detach()
     return render_pkg, parts
 
@@ -84,6 +88,8 @@ def densification_step(gaussians, render_pkg, opt, iteration, cameras_extent, wh
     `densification_interval`, opacity reset every `opacity_reset_interval`."""
     if iteration >= opt.densify_until_iter:
         return
+    if view_parallel is not None:
+        view_parallel.finish()       # a pipelined step may still be updating the SH tensors on its side stream
     with torch.no_grad():
         vis, radii = render_pkg["visibility_filter"], render_pkg["radii"]
         gaussians.max_radii2D[vis] = torch.max(gaussians.max_radii2D[vis], radii[vis].to(gaussians.max_radii2D.dtype))

@@ -7,16 +7,22 @@ multi-GPU row (section 8(e)): 58 f32 per Gaussian per step in a single grouped c
 reductions of the densification statistics right before a densify step so every replica takes
 identical clone / split / prune decisions.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 class ViewParallel:
-    def __init__(self, gaussians, process_group=None, average=True, force=False):
+    def __init__(self, gaussians, process_group=None, average=True, force=False, pipelined=None):
         self.g = gaussians
         self.pg = process_group
         self.average = average
         self.force = force          # run the collectives even at world size 1 (single-GPU rehearsal)
+        # pipelined step (RCCL + HIP only): see reduce_and_step(); GSR_DP_PIPELINE=0 switches it off
+        self.pipelined = (os.environ.get("GSR_DP_PIPELINE", "1") != "0") if pipelined is None else bool(pipelined)
+        self._side = None           # side stream of the SH update
+        self._pending = None        # event: SH update of the previous step finished
 
     @property
     def world_size(self):
@@ -32,17 +38,43 @@ class ViewParallel:
         perm = torch.randperm(len(views), generator=gen).tolist()
         return [views[i] for i in perm[self.rank::self.world_size]]
 
+    @staticmethod
+    def flat_gradient(grads):
+        """The fused rasterizer backward writes the six parameter gradients into ONE buffer
+        ([xyz | f_dc | opacity | scaling | rotation | f_rest], rasterizer.py).  Returns a 1-D tensor over that
+        buffer when `grads` are exactly such adjacent views (in any order, up to 3 floats of alignment padding
+        between them), else None."""
+        try:
+            st = grads[0].untyped_storage()
+            if any(g.untyped_storage().data_ptr() != st.data_ptr() or not g.is_contiguous() or g.dtype != grads[0].dtype
+                   for g in grads):
+                return None
+            spans = sorted((g.storage_offset(), g.numel()) for g in grads)
+            pos = spans[0][0]
+            for off, n in spans:
+                if not 0 <= off - pos < 4:       # segments may be padded to 16 bytes
+                    return None
+                pos = off + n
+            return torch.empty(0, dtype=grads[0].dtype, device=grads[0].device).set_(st, spans[0][0], (pos - spans[0][0],))
+        except (RuntimeError, AttributeError):
+            return None
+
     def allreduce_gradients(self):
-        """Average (or sum) the six parameter gradients across ranks IN PLACE.  On RCCL the six
-        all-reduces are issued as one group (ncclGroupStart/End through torch's coalescing
-        manager), i.e. one fused collective over 58 floats per Gaussian without a flatten /
-        un-flatten copy of the 232 MB (at 1 M Gaussians) bucket; on gloo (CPU tests) they run one
-        after the other."""
+        """Average (or sum) the six parameter gradients across ranks IN PLACE: one all-reduce over the flat
+        58-floats-per-Gaussian buffer the fused backward produced (232 MB at 1 M Gaussians, no flatten / un-flatten
+        copy); when the gradients are separate tensors, six all-reduces issued as one RCCL group."""
         if self.world_size == 1 and not self.force:
             return
         grads = [p.grad for p in self.g.parameters()]
         if any(gr is None for gr in grads):
             raise RuntimeError("allreduce_gradients() called before backward()")
+        flat = self.flat_gradient(grads)
+        if flat is not None:
+            use_avg = self.average and dist.get_backend(self.pg) == "nccl"
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, group=self.pg)
+            if self.average and not use_avg:
+                flat.mul_(1.0 / self.world_size)
+            return
         grads = [gr if gr.is_contiguous() else gr.contiguous() for gr in grads]
         backend = dist.get_backend(self.pg)
         use_avg = self.average and backend == "nccl"
@@ -64,6 +96,67 @@ class ViewParallel:
         for p, gr in zip(self.g.parameters(), grads):
             if p.grad is not gr:
                 p.grad = gr
+
+    def reduce_and_step(self, optimizer):
+        """all-reduce + optimiser step of one iteration.
+
+        Pipelined form (RCCL, HIP tensors, flat gradient buffer, FusedAdam): the buffer is reduced as two
+        collectives -- "geometry + dc" (13 floats per Gaussian) and "SH rest" (45) -- and the main stream only
+        waits for the first: it updates xyz / f_dc / opacity / scaling / rotation and is free to start the next
+        forward, whose geometry, sorting and binning phase (~0.4 ms at 1 M Gaussians) does not read the SH
+        coefficients.  The second collective and the Adam update of f_rest run on a side stream; the next forward
+        waits for them right before its SH colour pass (rasterizer.set_pending_param_event).  Anything else that
+        touches the parameters must call finish() first (densification, saving, evaluation renders do).
+        Falls back to allreduce_gradients() + optimizer.step() whenever a precondition is missing."""
+        params = list(self.g.parameters())
+        grads = [p.grad for p in params]
+        active = self.world_size > 1 or self.force
+        from .fused_adam import FusedAdam
+        ok = (active and self.pipelined and all(gr is not None and gr.is_cuda for gr in grads)
+              and dist.get_backend(self.pg) == "nccl" and isinstance(optimizer, FusedAdam))
+        flat = self.flat_gradient(grads) if ok else None
+        rest_p = getattr(self.g, "_features_rest", None)
+        if flat is None or rest_p is None or rest_p.grad is None or rest_p.grad.numel() == 0:
+            self.finish()
+            self.allreduce_gradients()
+            optimizer.step()
+            return
+        rest_g = rest_p.grad
+        # f_rest must be the tail of the buffer
+        if rest_g.storage_offset() + rest_g.numel() != flat.storage_offset() + flat.numel():
+            self.finish()
+            self.allreduce_gradients()
+            optimizer.step()
+            return
+        from . import rasterizer
+        dev = flat.device
+        self.finish()                                     # the previous step's SH update (normally long done)
+        n_head = flat.numel() - rest_g.numel()
+        head, tail = flat[:n_head], flat[n_head:]
+        op = dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM
+        w_head = dist.all_reduce(head, op=op, group=self.pg, async_op=True)
+        w_tail = dist.all_reduce(tail, op=op, group=self.pg, async_op=True)
+        w_head.wait()                                     # current stream waits for the first collective only
+        optimizer.step(only=[p for p in params if p is not rest_p])
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(self._side):
+            w_tail.wait()
+            optimizer.step(only=[rest_p], stream=self._side)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        flat.record_stream(self._side)                    # its memory may be reused only after the side stream is done
+        self._pending = ev
+        rasterizer.set_pending_param_event(dev, ev)
+
+    def finish(self):
+        """Make the current stream wait for the outstanding SH update of a pipelined step, if any."""
+        if self._pending is not None:
+            from . import rasterizer
+            dev = self.g.parameters()[0].device
+            rasterizer.wait_pending_params(dev)                      # un-park it (no-op if a forward consumed it)
+            torch.cuda.current_stream(dev).wait_event(self._pending)
+            self._pending = None
 
     def sync_densification_stats(self):
         """xyz_gradient_accum / denom are summed, max_radii2D is max-reduced."""

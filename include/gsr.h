@@ -51,6 +51,11 @@ enum {
     GSR_FLAG_FILTER_DEPTH_GRAD = 2, /* low-pass branch: dL/dz also added to dL/dTw.x,.y times s   */
     GSR_FLAGS_UPSTREAM = 3,
     GSR_FLAG_DEBUG_NO_CULL = 4,     /* test aid: ignore the per-wave cull rect (results are bit-identical) */
+    GSR_FLAG_COLOR_AFTER_ALLOC = 16, /* enqueue the SH colour pass AFTER the GSR_BUF_BINNING allocation callback
+                                        instead of before the instance-count read-back: the caller may make the
+                                        stream wait there for SH parameters that are still being updated on
+                                        another stream (pipelined data-parallel step); geometry inputs (means,
+                                        scales, rotations, opacities) must be final when gsr_forward is called */
     GSR_FLAG_RAW_PARAMS = 8         /* opacities are logits, scales are log-scales, rotations un-normalised:
                                        the activations of scene/gaussian_model.py:37-43 (sigmoid, exp,
                                        normalize) run inside the kernels and the gradients returned are

@@ -1,0 +1,93 @@
+"""Pipelined data-parallel step on one GPU (RCCL group of size 1, `force=True`): the collectives, the side
+stream, the deferred SH colour pass (GSR_FLAG_COLOR_AFTER_ALLOC) and the flat gradient buffer are all exercised;
+with one rank the averaged gradient is the gradient itself, so the parameters after a few steps must equal those of
+the plain single-GPU step bit for bit."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def nccl_world1(gpu_device):
+    if dist.is_initialized():
+        yield
+        return
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu_device)
+    yield
+    dist.destroy_process_group()
+
+
+def _run(gpu_device, mode, steps=4):
+    from gaussmart_amd.gaussian_model import GaussianModel
+    from gaussmart_amd.params import OptimizationParams, PipelineParams
+    from gaussmart_amd.synthetic import jittered_cameras, make_scene
+    from gaussmart_amd.trainer import training_step
+    from gaussmart_amd.view_parallel import ViewParallel
+    params, _ = make_scene(20000, 320, 200, seed=3)
+    cams = jittered_cameras(steps, 320, 200, seed=1, device=gpu_device)
+    gt = torch.rand(3, 200, 320, generator=torch.Generator().manual_seed(2)).to(gpu_device)
+    opt, pipe, bg = OptimizationParams(), PipelineParams(), torch.zeros(3, device=gpu_device)
+    m = GaussianModel(3, device=gpu_device)
+    m.create_from_params(params)
+    m.training_setup(opt)
+    vp = None
+    if mode == "pipelined":
+        vp = ViewParallel(m, force=True, pipelined=True)
+    elif mode == "flat":
+        vp = ViewParallel(m, force=True, pipelined=False)
+    losses = []
+    for i in range(steps):
+        _, parts = training_step(m, cams[i], gt, opt, pipe, bg, 10000 + i, view_parallel=vp)
+        losses.append(parts["total"])
+    if vp is not None:
+        vp.finish()
+    torch.cuda.synchronize()
+    return [p.detach().clone() for p in m.parameters()], [float(x) for x in losses], vp
+
+
+def test_pipelined_step_equals_plain_step(gpu_device, nccl_world1):
+    from gaussmart_amd import rasterizer
+    ref_p, ref_l, _ = _run(gpu_device, "plain")
+    for mode in ("flat", "pipelined"):
+        p, l, vp = _run(gpu_device, mode)
+        assert l == ref_l, mode
+        for a, b in zip(p, ref_p):
+            assert torch.equal(a, b), mode
+        assert not rasterizer._PENDING_PARAM_EVENT          # nothing left parked
+        if mode == "pipelined":
+            assert vp._side is not None                     # the side stream really was used
+
+
+def test_flat_gradient_buffer_from_fused_backward(gpu_device):
+    from gaussmart_amd.gaussian_model import GaussianModel
+    from gaussmart_amd.params import OptimizationParams, PipelineParams
+    from gaussmart_amd.synthetic import jittered_cameras, make_scene
+    from gaussmart_amd.trainer import training_step
+    from gaussmart_amd.view_parallel import ViewParallel
+    params, _ = make_scene(5000, 160, 96, seed=4)       # (an N that is not a multiple of 4 is covered by test_gpu_train)
+    cam = jittered_cameras(1, 160, 96, seed=1, device=gpu_device)[0]
+    gt = torch.rand(3, 96, 160, device=gpu_device)
+    m = GaussianModel(3, device=gpu_device)
+    m.create_from_params(params)
+    m.training_setup(OptimizationParams())
+    training_step(m, cam, gt, OptimizationParams(), PipelineParams(), torch.zeros(3, device=gpu_device), 10000,
+                  step_optimizer=False)
+    grads = [p.grad for p in m.parameters()]
+    flat = ViewParallel.flat_gradient(grads)
+    assert flat is not None and flat.numel() == sum(g.numel() for g in grads) == 5000 * 58
+    assert all(g.data_ptr() % 16 == 0 for g in grads)
+    rest = m._features_rest.grad
+    assert rest.storage_offset() + rest.numel() == flat.storage_offset() + flat.numel()   # f_rest is the tail

@@ -84,3 +84,41 @@ def test_view_parallel_world2(tmp_path):
         gaussian_renderer.GaussianRasterizer = old
     for k in range(6):
         torch.testing.assert_close(r[0]["grads"][k], 0.5 * (single[0][k] + single[1][k]), rtol=1e-5, atol=1e-9)
+
+
+def _flat_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gaussmart_amd.view_parallel import ViewParallel
+
+    class Toy:   # six parameters whose gradients are adjacent views of ONE buffer, as the fused backward makes them
+        def __init__(self):
+            g = torch.Generator().manual_seed(0)
+            self.ps = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in ((7, 3), (7, 1, 3), (7, 15, 3), (7, 1), (7, 2), (7, 4))]
+            self._features_rest = self.ps[2]
+        def parameters(self):
+            return self.ps
+
+    toy = Toy()
+    sizes = [toy.ps[i].numel() for i in (0, 1, 3, 4, 5, 2)]          # buffer order: f_rest last
+    flat = torch.arange(sum(sizes), dtype=torch.float32) * (rank + 1)
+    for i, part in zip((0, 1, 3, 4, 5, 2), torch.split(flat, sizes)):
+        toy.ps[i].grad = part.view_as(toy.ps[i])
+    vp = ViewParallel(toy)
+    base = vp.flat_gradient([p.grad for p in toy.ps])
+    assert base is not None and base.numel() == flat.numel() and base.data_ptr() == flat.data_ptr()
+    vp.allreduce_gradients()
+    # not adjacent -> no flat view; the per-tensor path still averages
+    loose = [torch.full_like(p, float(rank + 1)) for p in toy.ps]
+    assert vp.flat_gradient(loose) is None
+    torch.save({"flat": flat.clone()}, os.path.join(out_dir, f"flat{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_buffer_is_reduced_in_one_piece(tmp_path):
+    world, port = 2, _free_port()
+    mp.start_processes(_flat_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    r = [torch.load(os.path.join(tmp_path, f"flat{i}.pt"))["flat"] for i in range(world)]
+    want = torch.arange(r[0].numel(), dtype=torch.float32) * 1.5      # mean of x*1 and x*2
+    assert torch.equal(r[0], r[1]) and torch.allclose(r[0], want)
