@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -142,6 +143,12 @@ static uint32_t* pinned_counter() {
         slot = static_cast<uint32_t*>(p);
     }
     return slot;
+}
+
+// above this many bytes of worst-case gradient rows the backward reads the exact row count back (one host wait)
+static size_t exact_rows_threshold() {
+    const char* e = getenv("GSR_EXACT_ROWS_BYTES");      // read per call: tests flip it inside one process
+    return e && *e ? (size_t)strtoull(e, nullptr, 10) : (size_t(8) << 30);
 }
 
 static inline int bits_for(uint32_t n_values) {   // bits needed to represent 0..n_values-1
@@ -301,40 +308,54 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     const GsrImageLayout IL((int64_t)W * H);
 
     // Gradient rows: one 80-byte row per (instance, 4x4 pixel block the forward blended it into), DENSE in
-    // (emission index, quad, block) order.  Their number R <= 16 D is only known on the device (scan below), so
-    // the buffer is sized for the bound; only its first R rows are ever touched.
+    // (emission index, quad, block) order.  Their number R <= 16 D is only known on the device (scan below).
+    //   * normally the row buffer is sized for the bound and only its first R rows are ever touched: no host wait;
+    //   * when the bound is huge (> GSR_EXACT_ROWS_BYTES, default 8 GiB: tens of millions of instances) R is read
+    //     back first -- one host wait in the backward -- and the buffer is sized exactly (R is ~2.6 D in practice).
     const size_t n_inst = size_t(num_rendered > 0 ? num_rendered : 1);
-    const size_t rows_bytes = gsr_align(n_inst * GSR_SUBROWS * GSR_GROW_FLOATS * 4);
+    const bool wide = view->channels != 3;
+    const size_t row_bytes_each = size_t(GSR_GROW_FLOATS) * 4 + (wide ? size_t(view->channels) * 4 : 0);
     const size_t cnt_bytes = gsr_align(n_inst * 4);
     const size_t slot_bytes = gsr_align((n_inst + 1) * 4);
     const size_t scan_bytes = gsr_scan_workspace_bytes((int64_t)n_inst);
     const size_t sums_bytes = gsr_align(size_t(N > 0 ? N : 1) * GSR_GROW_FLOATS * 4);
-    const bool wide = view->channels != 3;
-    const size_t feat_bytes = wide ? gsr_align(n_inst * GSR_SUBROWS * size_t(view->channels) * 4) : 0;   // feature rows
-    char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH,
-                                             rows_bytes + cnt_bytes + slot_bytes + scan_bytes + sums_bytes + feat_bytes));
-    if (!scratch) { gsr_set_error("allocator returned NULL (gradient rows)"); return GSR_E_ALLOC; }
-    float* grad_rows = reinterpret_cast<float*>(scratch);
-    uint32_t* slot_cnt = reinterpret_cast<uint32_t*>(scratch + rows_bytes);
-    uint32_t* slot_off = reinterpret_cast<uint32_t*>(scratch + rows_bytes + cnt_bytes);
-    void* scan_ws = scratch + rows_bytes + cnt_bytes + slot_bytes;
-    float* row_sums = reinterpret_cast<float*>(scratch + rows_bytes + cnt_bytes + slot_bytes + scan_bytes);
-    float* feat_rows = wide ? reinterpret_cast<float*>(scratch + rows_bytes + cnt_bytes + slot_bytes + scan_bytes + sums_bytes)
-                            : nullptr;
+    char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, cnt_bytes + slot_bytes + scan_bytes + sums_bytes));
+    if (!scratch) { gsr_set_error("allocator returned NULL (backward scratch)"); return GSR_E_ALLOC; }
+    uint32_t* slot_cnt = reinterpret_cast<uint32_t*>(scratch);
+    uint32_t* slot_off = reinterpret_cast<uint32_t*>(scratch + cnt_bytes);
+    void* scan_ws = scratch + cnt_bytes + slot_bytes;
+    float* row_sums = reinterpret_cast<float*>(scratch + cnt_bytes + slot_bytes + scan_bytes);
 
+    size_t n_rows = n_inst * GSR_SUBROWS;       // the bound
+    const uint32_t* touch = at<uint32_t>(binning, BL.touch);
     if (num_rendered > 0) {
-        const uint32_t* touch = at<uint32_t>(binning, BL.touch);
         rc = gsr_launch_slot_count(num_rendered, touch, at<uint32_t>(binning, BL.inst_row), slot_cnt, s);
         if (rc != GSR_OK) return rc;
         rc = gsr_exclusive_scan_u32(slot_cnt, nullptr, slot_off, num_rendered, scan_ws, s);
         if (rc != GSR_OK) return rc;
+        if (n_rows * row_bytes_each > exact_rows_threshold()) {
+            uint32_t* r_host = pinned_counter();
+            if (!r_host) { gsr_set_error("hipHostMalloc failed (row-count read-back buffer)"); return GSR_E_HIP; }
+            GSR_HIP_CHECK(hipMemcpyAsync(r_host, slot_off + num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            GSR_HIP_CHECK(hipStreamSynchronize(s));
+            n_rows = size_t(*r_host > 0 ? *r_host : 1);
+        }
+    } else {
+        GSR_HIP_CHECK(hipMemsetAsync(slot_off, 0, 8, s));
+    }
+    const size_t rows_bytes = gsr_align(n_rows * GSR_GROW_FLOATS * 4);
+    const size_t feat_bytes = wide ? gsr_align(n_rows * size_t(view->channels) * 4) : 0;   // feature rows
+    char* rows_mem = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH2, rows_bytes + feat_bytes));
+    if (!rows_mem) { gsr_set_error("allocator returned NULL (gradient rows)"); return GSR_E_ALLOC; }
+    float* grad_rows = reinterpret_cast<float*>(rows_mem);
+    float* feat_rows = wide ? reinterpret_cast<float*>(rows_mem + rows_bytes) : nullptr;
+
+    if (num_rendered > 0) {
         rc = gsr_launch_render_bwd(*view, at<uint32_t>(binning, BL.ranges), at<uint32_t>(binning, BL.inst_row),
                                    at<float>(geom, GL.splat), touch, slot_off, at<float>(image, IL.final_T),
                                    at<uint32_t>(image, IL.n_contrib), dL_dcolor, dL_dallmap, grad_rows,
                                    wide ? g->colors_precomp : nullptr, at<uint32_t>(binning, BL.point_list), feat_rows, s);
         if (rc != GSR_OK) return rc;
-    } else {
-        GSR_HIP_CHECK(hipMemsetAsync(slot_off, 0, 8, s));
     }
     GsrGrads o = *grads;
     if (!g->shs) o.dL_dshs = nullptr;

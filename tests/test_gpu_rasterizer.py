@@ -211,6 +211,30 @@ def test_backward_parity_precomputed_colors_and_transmat(gpu_device):
         assert s["normwise"] < 1e-3 and s["median"] < 1e-4 and s["p99"] < 2e-3, (k, s)
 
 
+def test_exact_row_count_path_is_bit_identical(gpu_device, monkeypatch):
+    """Above GSR_EXACT_ROWS_BYTES of worst-case gradient rows the backward reads the row count back and sizes the
+    buffer exactly; forcing that path (threshold 0) must not change a single bit."""
+    from gaussmart_amd.rasterizer import GaussianRasterizer
+    p, cam = facing_scene(3000, 256, 192, seed=6)
+    a = activate(p)
+
+    def run():
+        ins = {k: a[k].clone().to(gpu_device).requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        m2d = torch.zeros(3000, 3, device=gpu_device, requires_grad=True)
+        c, r, am = GaussianRasterizer(hip_settings(cam, 3, (0.1, 0.2, 0.3), gpu_device))(
+            means3D=ins["means3D"], means2D=m2d, shs=ins["shs"], opacities=ins["opacities"], scales=ins["scales"],
+            rotations=ins["rotations"])
+        (c.square().sum() + am.sum()).backward()
+        torch.cuda.synchronize()
+        return [v.grad.clone() for v in ins.values()] + [m2d.grad.clone()]
+
+    ref = run()
+    monkeypatch.setenv("GSR_EXACT_ROWS_BYTES", "0")
+    exact = run()
+    for x, y in zip(ref, exact):
+        assert torch.equal(x, y)
+
+
 def test_clamp_quirk_reaches_opacity_gradient(gpu_device):
     p, cam = facing_scene(500, 128, 128, seed=3)
     a = activate(p)
