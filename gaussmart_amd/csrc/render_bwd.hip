@@ -65,10 +65,15 @@ struct RenderBwdParams {
 template <int FEAT16>
 __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) render_bwd_kernel(RenderBwdParams p) {
     __shared__ float4 s_rec_all[RB_WAVES][64 * 5];
+    // wide payload, up to 32 channels: features of the staged entries this quad touched, [entry][channel] (see render_fwd)
+    constexpr bool STAGE_FEAT = FEAT16 == 1 || FEAT16 == 2;
+    constexpr int NQ = STAGE_FEAT ? 4 * FEAT16 : 1;
+    __shared__ float4 s_feat_all[STAGE_FEAT ? RB_WAVES : 1][STAGE_FEAT ? 64 * 4 * FEAT16 : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     float4* s_rec = s_rec_all[wave];
+    float4* s_feat = s_feat_all[STAGE_FEAT ? wave : 0];
     const int tile_x = blockIdx.x, tile_y = blockIdx.y;
     const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
     const int grp = lane >> 4, l16 = lane & 15;   // DPP row = 4x4 pixel block, same mapping as render_fwd
@@ -161,6 +166,14 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
         // first gradient row of staged entry `lane` (its rows are dense, in (quad, block) order of the set bits)
         const uint32_t slot_of_lane = lane < nb ? p.slot_off[row_of_lane] : 0u;
         const uint32_t id_of_lane = ids_cur;          // Gaussian id of staged entry `lane` (wide payload only)
+        float4 ft[NQ];
+        const bool feat_needed = STAGE_FEAT && lane < nb && ((touch_of_lane >> (8 * wave)) & 0xFu) != 0u;
+        if (STAGE_FEAT) {   // issued before the next batch's prefetch, so waiting for them does not wait for it
+            const float4* fsrc = reinterpret_cast<const float4*>(p.feat + (size_t)id_of_lane * p.C);
+#pragma unroll
+            for (int k = 0; k < NQ; ++k)
+                if (feat_needed && 4 * k < p.C) ft[k] = fsrc[k];
+        }
         {   // prefetch the next (shallower) batch
             const int hi2 = lo, lo2 = max(0, hi2 - 64), cnt = hi2 - lo2;
             GSR_GATHER5(ids_nxt, cnt);
@@ -169,6 +182,11 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
             ids_cur = ids_nxt;
             const int lo3 = max(0, lo2 - 64), cnt3 = lo2 - lo3;
             ids_nxt = lane < cnt3 ? p.point_list[r0 + lo3 + lane] : 0u;
+        }
+        if (STAGE_FEAT) {
+#pragma unroll
+            for (int k = 0; k < NQ; ++k)
+                if (feat_needed && 4 * k < p.C) s_feat[lane * NQ + k] = ft[k];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -228,7 +246,8 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
                     q = c0 * dL_dpix0 + c1 * dL_dpix1 + c2 * dL_dpix2 + c_d * dL_ddepth + dL_daccum
                       + n0 * dL_dn0 + n1 * dL_dn1 + n2 * dL_dn2;
                 } else {
-                    const float4* f = reinterpret_cast<const float4*>(p.feat + (size_t)gid * p.C);
+                    const float4* f = STAGE_FEAT ? s_feat + j * NQ      // per-row LDS address
+                                                 : reinterpret_cast<const float4*>(p.feat + (size_t)gid * p.C);
                     float qc = 0.f;
 #pragma unroll
                     for (int k = 0; k < NF / 4; ++k) {

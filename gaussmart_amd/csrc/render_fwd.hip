@@ -55,15 +55,21 @@ __device__ __forceinline__ uint32_t row_or_step(uint32_t v) {
 }
 
 // FEAT16 = 0: three colour channels taken from the splat record (the reference's configuration).
-// FEAT16 = 1..4: up to 16*FEAT16 feature channels read from `feat` [N,C] by Gaussian id with wave-uniform
-// 16-byte loads (wide per-pixel payload); everything else is identical.
+// FEAT16 = 1..4: up to 16*FEAT16 feature channels read from `feat` [N,C] by Gaussian id, staged per batch in a
+// wave-private LDS tile (wide per-pixel payload); everything else is identical.
 template <int FEAT16>
 __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : 2) render_fwd_kernel(RenderFwdParams p) {
     __shared__ float4 s_rec_all[RF_WAVES][64 * 5];
+    // wide payload: the features of the staged entries that survive the cull, [entry][channel], wave-private
+    // (up to 32 channels: 8 KiB per wave; wider payloads would cut the occupancy to one wave per SIMD and read the
+    // features with wave-uniform scalar loads instead)
+    constexpr bool STAGE_FEAT = FEAT16 == 1 || FEAT16 == 2;
+    __shared__ float4 s_feat_all[STAGE_FEAT ? RF_WAVES : 1][STAGE_FEAT ? 64 * 4 * FEAT16 : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     float4* s_rec = s_rec_all[wave];
+    float4* s_feat = s_feat_all[STAGE_FEAT ? wave : 0];
     const int tile_x = blockIdx.x, tile_y = blockIdx.y;
     const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
     // lanes 16g..16g+15 (one DPP row) own the 4x4 pixel block g of the quad: the backward walks per-block lists
@@ -104,7 +110,7 @@ __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : 2) rend
         const int nb = min(64, n_list - base);
 s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_rec[lane * 5 + 3] = pf3; s_rec[lane * 5 + 4] = pf4;
         const uint32_t id_of_lane = ids_cur;
-        {   // prefetch the next batch while this one is composited
+        if (!STAGE_FEAT) {   // prefetch the next batch while this one is composited
             const int nxt = base + 64;
             const int cnt_nxt = nxt < n_list ? min(64, n_list - nxt) : 0;
             GSR_GATHER5(ids_nxt, cnt_nxt);
@@ -120,6 +126,28 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
             ov = no_cull || gsr_rect_overlaps_quad(__float_as_uint(r4.z), __float_as_uint(r4.w), qx0, qy0);
         }
         unsigned long long m = __ballot(ov);
+        if (STAGE_FEAT) {
+            // wide payload: lane l fetches the C features of staged entry l (if it survived the cull) and parks them in
+            // LDS; the loads are issued BEFORE the next batch's record prefetch, so waiting for them does not wait for it
+            constexpr int NQ = STAGE_FEAT ? 4 * FEAT16 : 1;
+            float4 ft[NQ];
+            const float4* fsrc = reinterpret_cast<const float4*>(p.feat + (size_t)id_of_lane * p.C);
+#pragma unroll
+            for (int k = 0; k < NQ; ++k)
+                if (ov && 4 * k < p.C) ft[k] = fsrc[k];
+            {
+                const int nxt = base + 64;
+                const int cnt_nxt = nxt < n_list ? min(64, n_list - nxt) : 0;
+                GSR_GATHER5(ids_nxt, cnt_nxt);
+                ids_cur = ids_nxt;
+                ids_nxt = nxt + 64 + lane < n_list ? p.point_list[r0 + nxt + 64 + lane] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < NQ; ++k)
+                if (ov && 4 * k < p.C) s_feat[lane * NQ + k] = ft[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         uint32_t mine_lo = 0u, mine_hi = 0u;   // staged splats THIS pixel blends (bit j)
         while (m) {
             // every lane is active here (the loop is wave-uniform), so the vote sees the whole wave
@@ -150,7 +178,8 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
                 C0 += a3.w * w; C1 += a4.x * w; C2 += a4.y * w;
             } else {
                 const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id_of_lane, j);   // wave-uniform
-                const float4* f = reinterpret_cast<const float4*>(p.feat + (size_t)gid * p.C);
+                const float4* f = STAGE_FEAT ? s_feat + j * (4 * FEAT16)       // LDS broadcast
+                                             : reinterpret_cast<const float4*>(p.feat + (size_t)gid * p.C);
 #pragma unroll
                 for (int k = 0; k < NF / 4; ++k) {
                     if (4 * k < p.C) {
