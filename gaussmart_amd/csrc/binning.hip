@@ -330,14 +330,13 @@ int gsr_launch_rank_gather(int N, const uint32_t* order, const uint2* tile_rect,
 
 // Load-balanced expansion: a wave owns 64 consecutive depth ranks, whose instances are one contiguous output
 // range.  Lane k parks rank k's (first output index, Gaussian id, tile rect) in LDS; then the 64 lanes fill the
-// range 64 outputs at a time, each finding its owner by binary search over the 64 first-indices -- the three
+// range 64 outputs at a time, each finding its owner by binary search over the 64 first-indices -- the two
 // output streams are written fully coalesced however unequal the rects are.
 __global__ void __launch_bounds__(256) emit_instances_kernel(int N, int gx,
                                                              const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ offs,
                                                              const uint2* __restrict__ rank_rect,
                                                              uint32_t* __restrict__ tile_keys,
-                                                             uint32_t* __restrict__ inst_vals,
                                                              uint32_t* __restrict__ emit_gid) {
     __shared__ uint32_t s_off[4][64], s_gid[4][64], s_xy[4][64], s_w[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -367,36 +366,31 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int N, int gx,
         const uint32_t i = o - s_off[wave][k], ww = s_w[wave][k], c = s_xy[wave][k];
         const uint32_t row = i / ww, col = i - row * ww;
         tile_keys[o] = ((c >> 16) + row) * (uint32_t)gx + (c & 0xFFFFu) + col;
-        inst_vals[o] = o;
         emit_gid[o] = s_gid[wave][k];
     }
 }
 
 int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const uint32_t* offs,
-                    const uint2* rank_rect, uint32_t* tile_keys, uint32_t* inst_vals,
-                    uint32_t* emit_gid, hipStream_t s) {
+                    const uint2* rank_rect, uint32_t* tile_keys, uint32_t* emit_gid, hipStream_t s) {
     if (N <= 0) return GSR_OK;
     (void)grid_y;
     GsrProfileScope prof(GSR_K_EMIT, s);
     hipLaunchKernelGGL(emit_instances_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, grid_x,
-                       order, offs, rank_rect, tile_keys, inst_vals, emit_gid);
+                       order, offs, rank_rect, tile_keys, emit_gid);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }
 
-// Per sorted instance: Gaussian id, emission index and the tile ranges.  (The 80-byte records themselves are
+// Per sorted instance: Gaussian id and the tile ranges (the emission index is the sort's own value output).  (The 80-byte records themselves are
 // NOT copied into list order any more: the render kernels gather them by id, see render_fwd.hip.)
 __global__ void __launch_bounds__(256) finalize_bins_kernel(int D, const uint32_t* __restrict__ tile_sorted,
-                                                            const uint32_t* __restrict__ perm,
+                                                            const uint32_t* __restrict__ inst_row,
                                                             const uint32_t* __restrict__ emit_gid,
                                                             uint32_t* __restrict__ point_list,
-                                                            uint32_t* __restrict__ inst_row,
                                                             uint32_t* __restrict__ ranges) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D) return;
-    const uint32_t e = perm[i];
-    point_list[i] = emit_gid[e];
-    inst_row[i] = e;
+    point_list[i] = emit_gid[inst_row[i]];   // inst_row = the tile sort's value output (emission index per entry)
     const uint32_t t = tile_sorted[i];
     if (i == 0) ranges[2 * t] = 0;
     else {
@@ -406,14 +400,13 @@ __global__ void __launch_bounds__(256) finalize_bins_kernel(int D, const uint32_
     if (i == D - 1) ranges[2 * t + 1] = D;
 }
 
-int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted, const uint32_t* perm,
-                             const uint32_t* emit_gid, uint32_t* point_list, uint32_t* inst_row, uint32_t* ranges,
-                             hipStream_t s) {
+int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted, const uint32_t* inst_row,
+                             const uint32_t* emit_gid, uint32_t* point_list, uint32_t* ranges, hipStream_t s) {
     GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
     if (D <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_FINALIZE, s);
     hipLaunchKernelGGL(finalize_bins_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, D,
-                       tile_keys_sorted, perm, emit_gid, point_list, inst_row, ranges);
+                       tile_keys_sorted, inst_row, emit_gid, point_list, ranges);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

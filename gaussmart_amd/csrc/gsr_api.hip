@@ -260,20 +260,19 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         char* sc2 = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH2, 7 * db + sort_ws_d));
         if (!sc2) { gsr_set_error("allocator returned NULL (scratch2)"); return GSR_E_ALLOC; }
         uint32_t* tile_keys = reinterpret_cast<uint32_t*>(sc2);
-        uint32_t* inst_vals = reinterpret_cast<uint32_t*>(sc2 + db);
         uint32_t* emit_gid = reinterpret_cast<uint32_t*>(sc2 + 2 * db);
         uint32_t* tile_sorted = reinterpret_cast<uint32_t*>(sc2 + 3 * db);
-        uint32_t* perm = reinterpret_cast<uint32_t*>(sc2 + 4 * db);
+        uint32_t* perm = inst_row;   // the sorted values ARE the emission indices of the list entries: sort straight into place
         uint32_t* tk_tmp = reinterpret_cast<uint32_t*>(sc2 + 5 * db);
         uint32_t* tv_tmp = reinterpret_cast<uint32_t*>(sc2 + 6 * db);
         void* sort_ws2 = sc2 + 7 * db;
-        rc = gsr_launch_emit(N, gx, gy, order, offs, rank_rect,
-                             tile_keys, inst_vals, emit_gid, s);
+        rc = gsr_launch_emit(N, gx, gy, order, offs, rank_rect, tile_keys, emit_gid, s);
         if (rc != GSR_OK) return rc;
-        rc = gsr_radix_sort_pairs(tile_keys, inst_vals, tile_sorted, perm, tk_tmp, tv_tmp, D, 0,
+        // values = emission indices 0..D-1: the sort generates them itself (vals_in = NULL)
+        rc = gsr_radix_sort_pairs(tile_keys, nullptr, tile_sorted, perm, tk_tmp, tv_tmp, D, 0,
                                   bits_for((uint32_t)n_tiles), sort_ws2, s);
         if (rc != GSR_OK) return rc;
-        rc = gsr_launch_finalize_bins((int)D, n_tiles, tile_sorted, perm, emit_gid, point_list, inst_row, ranges, s);
+        rc = gsr_launch_finalize_bins((int)D, n_tiles, tile_sorted, inst_row, emit_gid, point_list, ranges, s);
         if (rc != GSR_OK) return rc;
     } else {
         GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));

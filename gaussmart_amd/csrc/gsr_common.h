@@ -120,11 +120,10 @@ int gsr_launch_preprocess_color(const GsrView& v, const GsrGaussians& g, float* 
 int gsr_launch_rank_gather(int N, const uint32_t* order, const uint2* tile_rect, uint2* rank_rect, uint32_t* rank_cnt,
                            hipStream_t s);
 int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const uint32_t* offs,
-                    const uint2* rank_rect, uint32_t* tile_keys, uint32_t* inst_vals,
-                    uint32_t* emit_gid, hipStream_t s);
+                    const uint2* rank_rect, uint32_t* tile_keys, uint32_t* emit_gid, hipStream_t s);
 int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted,
-                             const uint32_t* perm, const uint32_t* emit_gid,
-                             uint32_t* point_list, uint32_t* inst_row, uint32_t* ranges, hipStream_t s);
+                             const uint32_t* inst_row, const uint32_t* emit_gid,
+                             uint32_t* point_list, uint32_t* ranges, hipStream_t s);
 int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* splat,
                           float* final_T, uint32_t* n_contrib, float* out_color,
                           float* out_allmap, uint8_t* touch, const float* feat, const uint32_t* point_list,

@@ -1,58 +1,12 @@
-// wave64 reductions shared by the backward compositing kernels (gfx950 only).
+// DPP-row (16-lane) reductions shared by the backward kernels (gfx950 only).
 #pragma once
 #include "gsr_common.h"
 
-// ---- wave64 reductions -----------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_move(float v) {
     // lanes whose source is disabled/out of range receive 0 (bound_ctrl)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
 }
-typedef unsigned int gsr_u2 __attribute__((ext_vector_type(2)));
-
-// "Transposed butterfly": sums 16 per-lane values over the 64 lanes in 6 stages while HALVING the
-// number of live registers at each of the first four (gfx950 v_permlane32_swap / v_permlane16_swap,
-// then DPP row_ror:8 and row_half_mirror with a select).  ~50 VALU instead of 16 x 6 DPP steps.
-// On return every lane l holds the wave total of v[l >> 2].
-__device__ __forceinline__ float wave_sum16_transposed(const float (&v)[16], int lane) {
-    float r[8], q[4], p[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {      // bit 5: lanes < 32 keep v[i], lanes >= 32 keep v[i+8]
-        const gsr_u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
-        r[i] = __uint_as_float(t.x) + __uint_as_float(t.y);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {      // bit 4: even rows keep r[i], odd rows keep r[i+4]
-        const gsr_u2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[i]), __float_as_uint(r[i + 4]), false, false);
-        q[i] = __uint_as_float(t.x) + __uint_as_float(t.y);
-    }
-    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {      // bit 3: partner is lane ^ 8 (row_ror:8)
-        const float keep = b3 ? q[i + 2] : q[i], send = b3 ? q[i] : q[i + 2];
-        p[i] = keep + dpp_move<0x128, 0xf>(send);
-    }
-    {                                   // bit 2: partner is lane ^ 7 inside each group of 8 (row_half_mirror)
-        const float keep = b2 ? p[1] : p[0], send = b2 ? p[0] : p[1];
-        p[0] = keep + dpp_move<0x141, 0xf>(send);
-    }
-    p[0] += dpp_move<0xB1, 0xf>(p[0]);  // quad_perm [1,0,3,2]
-    p[0] += dpp_move<0x4E, 0xf>(p[0]);  // quad_perm [2,3,0,1]
-    return p[0];
-}
-// Two values: on return lanes 16..31 hold the wave total of a, lanes 48..63 that of b.
-__device__ __forceinline__ float wave_sum2(float a, float b) {
-    const gsr_u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    float v = __uint_as_float(t.x) + __uint_as_float(t.y);
-    v += dpp_move<0xB1, 0xf>(v);
-    v += dpp_move<0x4E, 0xf>(v);
-    v += dpp_move<0x141, 0xf>(v);   // row_half_mirror
-    v += dpp_move<0x140, 0xf>(v);   // row_mirror: every lane holds its row's sum
-    v += dpp_move<0x142, 0xa>(v);   // row_bcast:15: rows 1 and 3 add the previous row
-    return v;
-}
-
-
 // ---- 16-lane (one DPP row) reductions: no cross-row traffic at all ------------------------------------
 // Transposed butterfly over the 16 lanes of a row: 8 + 4 + 2 + 1 adds, each fused with its DPP move.
 // On return lane l (0..15 inside its row) holds the ROW total of v[l].
