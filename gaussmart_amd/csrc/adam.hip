@@ -9,6 +9,15 @@
 #include "gsr_common.h"
 
 #define AD_BLOCK 256
+typedef float ad_f4 __attribute__((ext_vector_type(4)));   // the non-temporal builtins want a native vector type
+__device__ __forceinline__ float4 nt_load4(const float* base, long long i) {
+    const ad_f4 t = __builtin_nontemporal_load(reinterpret_cast<const ad_f4*>(base) + i);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void nt_store4(float* base, long long i, const float4 v) {
+    ad_f4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<ad_f4*>(base) + i);
+}
 #define AD_MAX_TENSORS 8
 
 struct AdamBatch {
@@ -40,16 +49,18 @@ __global__ void __launch_bounds__(AD_BLOCK) adam_kernel(AdamBatch b) {
     const long long n4 = vec ? n / 4 : 0;
     const long long stride = (long long)gridDim.x * AD_BLOCK;
     for (long long i = (long long)blockIdx.x * AD_BLOCK + threadIdx.x; i < n4; i += stride) {
+        // gradients and moments are touched once per step: non-temporal, so that they do not evict the parameters
+        // (which the next forward reads) from the 256 MB Infinity Cache
         float4 pp = reinterpret_cast<float4*>(p)[i];
-        const float4 gg = reinterpret_cast<const float4*>(g)[i];
-        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 gg = nt_load4(g, i);
+        float4 mm = nt_load4(m, i), vv = nt_load4(v, i);
         adam_one(pp.x, gg.x, mm.x, vv.x, b.omb1, b.beta2, b.omb2, b.eps, ss, ib);
         adam_one(pp.y, gg.y, mm.y, vv.y, b.omb1, b.beta2, b.omb2, b.eps, ss, ib);
         adam_one(pp.z, gg.z, mm.z, vv.z, b.omb1, b.beta2, b.omb2, b.eps, ss, ib);
         adam_one(pp.w, gg.w, mm.w, vv.w, b.omb1, b.beta2, b.omb2, b.eps, ss, ib);
         reinterpret_cast<float4*>(p)[i] = pp;
-        reinterpret_cast<float4*>(m)[i] = mm;
-        reinterpret_cast<float4*>(v)[i] = vv;
+        nt_store4(m, i, mm);
+        nt_store4(v, i, vv);
     }
     for (long long i = n4 * 4 + (long long)blockIdx.x * AD_BLOCK + threadIdx.x; i < n; i += stride) {
         float pp = p[i], mm = m[i], vv = v[i];
