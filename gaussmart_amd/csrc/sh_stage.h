@@ -24,20 +24,32 @@ __device__ __forceinline__ void sh_copy_rows(float* wl, float* gptr, int n_float
     int row = e / row_f, col = e - row * row_f;
     const int q_step = 256 / row_f, r_step = 256 - q_step * row_f;
     float4* g4 = reinterpret_cast<float4*>(gptr);
-    for (int v = lane; v < n_vec; v += 64) {
-        float4 d;
-        if (TO_LDS) d = g4[v];
-        int r = row, c = col;
-        float* vals = reinterpret_cast<float*>(&d);
+    // four 16-byte vectors per lane and round: all four global loads are in flight before the first LDS write
+    // (one load per round left the wave waiting ~12 memory latencies in a row for a 64 x 45-float block)
+    constexpr int U = 4;
+    for (int v0 = lane; v0 < n_vec; v0 += 64 * U) {
+        float4 d[U];
+        if (TO_LDS) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (TO_LDS) wl[r * SH_ROW_FLOATS + col0 + c] = vals[k];
-            else vals[k] = wl[r * SH_ROW_FLOATS + col0 + c];
-            if (++c == row_f) { c = 0; ++r; }
+            for (int u = 0; u < U; ++u)
+                if (v0 + 64 * u < n_vec) d[u] = g4[v0 + 64 * u];
         }
-        if (!TO_LDS) g4[v] = d;
-        row += q_step; col += r_step;
-        if (col >= row_f) { col -= row_f; ++row; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (v0 + 64 * u < n_vec) {
+                int r = row, c = col;
+                float* vals = reinterpret_cast<float*>(&d[u]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (TO_LDS) wl[r * SH_ROW_FLOATS + col0 + c] = vals[k];
+                    else vals[k] = wl[r * SH_ROW_FLOATS + col0 + c];
+                    if (++c == row_f) { c = 0; ++r; }
+                }
+                if (!TO_LDS) g4[v0 + 64 * u] = d[u];
+            }
+            row += q_step; col += r_step;
+            if (col >= row_f) { col -= row_f; ++row; }
+        }
     }
     for (int t = (n_vec << 2) + lane; t < n_floats; t += 64) {      // < 4 trailing floats
         const int r = t / row_f, c = t - r * row_f;
