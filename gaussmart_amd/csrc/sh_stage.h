@@ -26,7 +26,7 @@ __device__ __forceinline__ void sh_copy_rows(float* wl, float* gptr, int n_float
     float4* g4 = reinterpret_cast<float4*>(gptr);
     // four 16-byte vectors per lane and round: all four global loads are in flight before the first LDS write
     // (one load per round left the wave waiting ~12 memory latencies in a row for a 64 x 45-float block)
-    constexpr int U = 4;
+    constexpr int U = 12;
     for (int v0 = lane; v0 < n_vec; v0 += 64 * U) {
         float4 d[U];
         if (TO_LDS) {
