@@ -388,16 +388,32 @@ __global__ void __launch_bounds__(256) finalize_bins_kernel(int D, const uint32_
                                                             const uint32_t* __restrict__ emit_gid,
                                                             uint32_t* __restrict__ point_list,
                                                             uint32_t* __restrict__ ranges) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= D) return;
-    point_list[i] = emit_gid[inst_row[i]];   // inst_row = the tile sort's value output (emission index per entry)
-    const uint32_t t = tile_sorted[i];
-    if (i == 0) ranges[2 * t] = 0;
-    else {
-        const uint32_t tp = tile_sorted[i - 1];
-        if (tp != t) { ranges[2 * tp + 1] = i; ranges[2 * t] = i; }
+    // four entries per thread, one block-stride apart: the four dependent gathers (entry -> emission index ->
+    // Gaussian id) are in flight together instead of one per thread
+    const int i0 = blockIdx.x * (blockDim.x * 4) + threadIdx.x;
+    uint32_t e[4], t[4], tp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256;
+        e[u] = 0; t[u] = 0; tp[u] = 0;
+        if (i < D) {
+            e[u] = inst_row[i];   // inst_row = the tile sort's value output (emission index per entry)
+            t[u] = tile_sorted[i];
+            tp[u] = i > 0 ? tile_sorted[i - 1] : 0xFFFFFFFFu;
+        }
     }
-    if (i == D - 1) ranges[2 * t + 1] = D;
+    uint32_t g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) g[u] = i0 + u * 256 < D ? emit_gid[e[u]] : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256;
+        if (i >= D) continue;
+        point_list[i] = g[u];
+        if (i == 0) ranges[2 * t[u]] = 0;
+        else if (tp[u] != t[u]) { ranges[2 * tp[u] + 1] = i; ranges[2 * t[u]] = i; }
+        if (i == D - 1) ranges[2 * t[u] + 1] = D;
+    }
 }
 
 int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted, const uint32_t* inst_row,
@@ -405,7 +421,7 @@ int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorte
     GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
     if (D <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_FINALIZE, s);
-    hipLaunchKernelGGL(finalize_bins_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, D,
+    hipLaunchKernelGGL(finalize_bins_kernel, dim3((unsigned)((D + 1023) / 1024)), dim3(256), 0, s, D,
                        tile_keys_sorted, inst_row, emit_gid, point_list, ranges);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
