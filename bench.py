@@ -212,6 +212,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the reference's own `iter_time` bracket (train.py:91,145: forward + loss + backward, no optimiser step),
+    # measured AFTER the timed region with device events on a few extra steps (rank 0, informational)
+    ref_iter_ms = None
+    if rank == 0:
+        n_ref = min(20, max(args.steps, 1))
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ref)]
+        for a, b in ev:
+            a.record()
+            training_step(model, cam, gt, opt, pipe, bg, base_iter + args.warmup + args.steps, step_optimizer=False)
+            b.record()
+            model.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        ref_iter_ms = sorted(a.elapsed_time(b) for a, b in ev)[n_ref // 2]
+    if world > 1:
+        dist.barrier()
+
     if rank == 0:
         # measured instance count of this frame (plugs into the algorithmic byte model)
         a = activate({k: p.detach() for k, p in zip(("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation"),
@@ -241,6 +257,7 @@ def main():
                          "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, same scene; "
                                            "2 x FETCH_SIZE + WRITE_SIZE)",
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per_kernel[dom]},
+            "reference_iter_time_ms": ref_iter_ms,    # median of the reference's fwd+loss+bwd bracket (no Adam)
             "kernel_ms": {k: round(v, 4) for k, v in per_kernel.items()},
             "kernel_ms_warmup": {k: round(v, 4) for k, v in warm.items()},
             "kernel_ms_per_step": {k: round(ms / args.steps, 4) for k, (ms, n) in prof.items() if n},
