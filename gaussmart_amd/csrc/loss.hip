@@ -229,8 +229,24 @@ __global__ void __launch_bounds__(256) objective_finish_kernel(const float* __re
                                                                float* __restrict__ out) {
     __shared__ float red[4][256];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int i = threadIdx.x; i < n_pl; i += 256) { s0 += pl[2 * i]; s1 += pl[2 * i + 1]; }
-    for (int i = threadIdx.x; i < n_pr; i += 256) { s2 += pr[2 * i]; s3 += pr[2 * i + 1]; }
+    // eight independent 8-byte loads in flight per thread and round (one at a time made this 1-block kernel wait
+    // ~30 memory latencies in a row); the per-thread summation order is unchanged
+    const float2* pl2 = reinterpret_cast<const float2*>(pl);
+    const float2* pr2 = reinterpret_cast<const float2*>(pr);
+    for (int base = threadIdx.x; base < n_pl; base += 256 * 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = base + 256 * u; v[u] = i < n_pl ? pl2[i] : make_float2(0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s0 += v[u].x; s1 += v[u].y; }
+    }
+    for (int base = threadIdx.x; base < n_pr; base += 256 * 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = base + 256 * u; v[u] = i < n_pr ? pr2[i] : make_float2(0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s2 += v[u].x; s3 += v[u].y; }
+    }
     red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2; red[3][threadIdx.x] = s3;
     __syncthreads();
     for (int d = 128; d > 0; d >>= 1) {
