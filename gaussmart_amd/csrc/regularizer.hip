@@ -40,18 +40,36 @@ __device__ __forceinline__ float3 rg_cross(float3 a, float3 b) {
     return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 
-// stage surf_depth of the tile plus `halo` pixels into LDS (0 outside the image)
+// stage surf_depth of the tile plus `halo` pixels into LDS (0 outside the image).  (16 + 2 HALO)^2 <= 512 elements:
+// every thread issues the loads of BOTH its elements before the first LDS write (they are independent; one element at
+// a time left the block waiting two memory latencies in a row).
 template <int HALO>
 __device__ __forceinline__ void rg_stage_depth(const RegParams& p, const float* __restrict__ am, float (*sd)[RG_T + 2 * HALO + 1],
                                                int x0, int y0) {
     constexpr int R = RG_T + 2 * HALO;
+    static_assert(R * R <= 512, "two elements per thread");
     const size_t HW = (size_t)p.W * p.H;
-    for (int i = threadIdx.x; i < R * R; i += 256) {
+    float D[2], A[2], M[2];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + 256 * u;
         const int r = i / R, q = i - r * R;
         const int gy = y0 + r - HALO, gx = x0 + q - HALO;
-        float v = 0.f;
-        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = rg_surf_depth(am, HW, (size_t)gy * p.W + gx, p.depth_ratio);
-        sd[r][q] = v;
+        ok[u] = i < R * R && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        D[u] = 0.f; A[u] = 1.f; M[u] = 0.f;
+        if (ok[u]) {
+            const size_t o = (size_t)gy * p.W + gx;
+            D[u] = am[o]; A[u] = am[HW + o]; M[u] = am[5 * HW + o];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        if (i < R * R) {
+            const int r = i / R, q = i - r * R;
+            sd[r][q] = ok[u] ? (1.f - p.depth_ratio) * rg_nan_to_num(D[u] / A[u]) + p.depth_ratio * rg_nan_to_num(M[u]) : 0.f;
+        }
     }
 }
 
@@ -63,24 +81,28 @@ __global__ void __launch_bounds__(256) reg_fwd_kernel(RegParams p, const float* 
     const int x0 = blockIdx.x * RG_T, y0 = blockIdx.y * RG_T;
     const int x = x0 + tx, y = y0 + ty;
     const size_t HW = (size_t)p.W * p.H;
+    // this pixel's own planes are requested before the staging loads are waited for
+    const bool in_img = x < p.W && y < p.H;
+    const bool interior = in_img && x >= 1 && x <= p.W - 2 && y >= 1 && y <= p.H - 2;
+    const size_t o = in_img ? (size_t)y * p.W + x : 0;
+    float alpha = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, dist = 0.f;
+    if (interior) { alpha = am[HW + o]; n0 = am[2 * HW + o]; n1 = am[3 * HW + o]; n2 = am[4 * HW + o]; }
+    if (in_img) dist = am[6 * HW + o];
     rg_stage_depth<1>(p, am, sd, x0, y0);
     __syncthreads();
-    float err = 0.f, dist = 0.f;
-    if (x < p.W && y < p.H) {
-        const size_t o = (size_t)y * p.W + x;
+    float err = 0.f;
+    if (in_img) {
         float dotp = 0.f;
-        if (x >= 1 && x <= p.W - 2 && y >= 1 && y <= p.H - 2) {
+        if (interior) {
             const float3 ru = rg_ray(p, x, y + 1), rd = rg_ray(p, x, y - 1), rr = rg_ray(p, x + 1, y), rl = rg_ray(p, x - 1, y);
             const float du = sd[ty + 2][tx + 1], dd = sd[ty][tx + 1], dr = sd[ty + 1][tx + 2], dl = sd[ty + 1][tx];
             const float3 dx = make_float3(du * ru.x - dd * rd.x, du * ru.y - dd * rd.y, du * ru.z - dd * rd.z);
             const float3 dy = make_float3(dr * rr.x - dl * rl.x, dr * rr.y - dl * rl.y, dr * rr.z - dl * rl.z);
             const float3 c = rg_cross(dx, dy);
             const float inv = 1.0f / fmaxf(sqrtf(c.x * c.x + c.y * c.y + c.z * c.z), 1e-12f);
-            const float alpha = am[HW + o];
-            dotp = (am[2 * HW + o] * c.x + am[3 * HW + o] * c.y + am[4 * HW + o] * c.z) * inv * alpha;
+            dotp = (n0 * c.x + n1 * c.y + n2 * c.z) * inv * alpha;
         }
         err = 1.0f - dotp;
-        dist = am[6 * HW + o];
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { err += __shfl_down(err, d, 64); dist += __shfl_down(dist, d, 64); }
@@ -106,16 +128,40 @@ __global__ void __launch_bounds__(256) reg_bwd_kernel(RegParams p, const float* 
     const float gs = grad_scale[0];
     const float kn = lambda_normal * inv_n * gs, kd = lambda_dist * inv_n * gs;
 
+    // phase-1 items of this thread (tile + halo 1 = 324 pixels: at most two per thread) and the final pixel: their
+    // planes are requested before the staging loads are waited for
+    constexpr int R1 = RG_T + 2;
+    float p1_alpha[2], p1_n0[2], p1_n1[2], p1_n2[2];
+    bool p1_in[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        const int r = i / R1, q = i - r * R1;
+        const int y = y0 + r - 1, x = x0 + q - 1;
+        p1_in[u] = i < R1 * R1 && x >= 1 && x <= p.W - 2 && y >= 1 && y <= p.H - 2;
+        p1_alpha[u] = 0.f; p1_n0[u] = 0.f; p1_n1[u] = 0.f; p1_n2[u] = 0.f;
+        if (p1_in[u]) {
+            const size_t o = (size_t)y * p.W + x;
+            p1_alpha[u] = am[HW + o]; p1_n0[u] = am[2 * HW + o]; p1_n1[u] = am[3 * HW + o]; p1_n2[u] = am[4 * HW + o];
+        }
+    }
+    const int fx = x0 + tx, fy = y0 + ty;
+    const bool f_in = fx < p.W && fy < p.H;
+    const size_t fo = f_in ? (size_t)fy * p.W + fx : 0;
+    float fD = 0.f, fA = 1.f, fmed = 0.f;
+    if (f_in) { fD = am[fo]; fA = am[HW + fo]; fmed = am[5 * HW + fo]; }
+
     rg_stage_depth<2>(p, am, sd, x0, y0);
     __syncthreads();
     // phase 1: for every pixel q of the tile + halo 1, the gradient w.r.t. its two finite differences
-    constexpr int R1 = RG_T + 2;
-    for (int i = threadIdx.x; i < R1 * R1; i += 256) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        if (i >= R1 * R1) continue;
         const int r = i / R1, q = i - r * R1;
         const int y = y0 + r - 1, x = x0 + q - 1;
         float3 gdx = make_float3(0.f, 0.f, 0.f), gdy = gdx;
-        if (x >= 1 && x <= p.W - 2 && y >= 1 && y <= p.H - 2) {
-            const size_t o = (size_t)y * p.W + x;
+        if (p1_in[u]) {
             const float3 ru = rg_ray(p, x, y + 1), rd = rg_ray(p, x, y - 1), rr = rg_ray(p, x + 1, y), rl = rg_ray(p, x - 1, y);
             const float du = sd[r + 2][q + 1], dd = sd[r][q + 1], dr = sd[r + 1][q + 2], dl = sd[r + 1][q];   // sd has halo 2
             const float3 dx = make_float3(du * ru.x - dd * rd.x, du * ru.y - dd * rd.y, du * ru.z - dd * rd.z);
@@ -125,9 +171,9 @@ __global__ void __launch_bounds__(256) reg_bwd_kernel(RegParams p, const float* 
             if (len > 1e-12f) {
                 const float il = 1.0f / len;
                 const float3 s = make_float3(c.x * il, c.y * il, c.z * il);
-                const float alpha = am[HW + o];
+                const float alpha = p1_alpha[u];
                 // L_q = -kn * alpha * (N . s)  (alpha detached)
-                const float3 g = make_float3(-kn * alpha * am[2 * HW + o], -kn * alpha * am[3 * HW + o], -kn * alpha * am[4 * HW + o]);
+                const float3 g = make_float3(-kn * alpha * p1_n0[u], -kn * alpha * p1_n1[u], -kn * alpha * p1_n2[u]);
                 const float sg_ = s.x * g.x + s.y * g.y + s.z * g.z;
                 const float3 gc = make_float3((g.x - s.x * sg_) * il, (g.y - s.y * sg_) * il, (g.z - s.z * sg_) * il);
                 gdx = rg_cross(dy, gc);      // dL/ddx = dy x dL/dc
@@ -138,9 +184,9 @@ __global__ void __launch_bounds__(256) reg_bwd_kernel(RegParams p, const float* 
         sg[3][r][q] = gdy.x; sg[4][r][q] = gdy.y; sg[5][r][q] = gdy.z;
     }
     __syncthreads();
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= p.W || y >= p.H) return;
-    const size_t o = (size_t)y * p.W + x;
+    const int x = fx, y = fy;
+    if (!f_in) return;
+    const size_t o = fo;
     const int r = ty + 1, q = tx + 1;     // position inside the halo-1 arrays
     // P(p) is the "upper" point of the pixel above... : dx(q) = P[y+1] - P[y-1]
     //   pixel (y-1) uses P(p) with +, pixel (y+1) with -, same for x through dy
@@ -151,7 +197,7 @@ __global__ void __launch_bounds__(256) reg_bwd_kernel(RegParams p, const float* 
     const float3 ray = rg_ray(p, x, y);
     const float g_sd = gP.x * ray.x + gP.y * ray.y + gP.z * ray.z;
 
-    const float D = am[o], A = am[HW + o], med = am[5 * HW + o];
+    const float D = fD, A = fA, med = fmed;
     const float e = D / A;
     const bool e_ok = !(isnan(e) || isinf(e));
     const float g_e = (1.f - p.depth_ratio) * g_sd;
