@@ -5,7 +5,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import surfel_ref as O
 from gaussmart_amd.synthetic import make_scene, activate
 from gaussmart_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_debug
-from gaussmart_amd import _lib
 
 def osettings(cam, deg, dt, bg):
     return O.Settings(cam.image_height, cam.image_width, math.tan(cam.FoVx/2), math.tan(cam.FoVy/2),

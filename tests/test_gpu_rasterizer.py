@@ -10,7 +10,6 @@ Tolerances (north_star: 1e-4 relative fp32; integer work bit-exact):
     <= 1e-4, 99th percentile <= 2e-3 (single-pixel threshold flips between fp32 and fp64 bound
     the tail, see DESIGN.md "parity").
 """
-import math
 
 import numpy as np
 import pytest

@@ -1,6 +1,5 @@
 """Fused surface regularizers (HIP) vs the oracle restatement of the reference's allmap
 post-processing + depth_to_normal + normal / distortion losses, and render()'s own torch maps."""
-import math
 
 import numpy as np
 import pytest

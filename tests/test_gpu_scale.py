@@ -2,7 +2,6 @@
 are not available offline): size-independent properties + determinism + finite gradients."""
 import math
 
-import numpy as np
 import pytest
 import torch
 

@@ -4,9 +4,8 @@ channel-count agnostic.  Tolerances as in test_gpu_rasterizer.py (fp32 kernels v
 import pytest
 import torch
 
-from conftest import facing_scene, hip_settings, oracle_settings
+from conftest import facing_scene, hip_settings
 from gaussmart_amd.synthetic import activate
-from oracle import surfel_ref as O
 from test_gpu_rasterizer import _grad_compare
 
 pytestmark = pytest.mark.gpu

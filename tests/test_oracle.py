@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import oracle_settings, facing_scene
+from conftest import oracle_settings
 from gaussmart_amd.synthetic import make_scene, activate
 from oracle import surfel_ref as O
 

@@ -3,7 +3,6 @@ views, one flat all-reduce of the per-Gaussian gradients, replicated densificati
 import os
 import socket
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
