@@ -129,6 +129,13 @@ def lib():
         L.gsr_adam_step.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_float),
                                     C.POINTER(C.c_float), C.c_double, C.c_double, C.c_double, C.c_void_p]
+        L.gsr_compact_workspace_bytes.restype = C.c_size_t
+        L.gsr_compact_workspace_bytes.argtypes = [C.c_int64]
+        L.gsr_compact_plan.restype = C.c_int32
+        L.gsr_compact_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_void_p]
+        L.gsr_compact_apply.restype = C.c_int32
+        L.gsr_compact_apply.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gsr_profile_enable.restype = None
         L.gsr_profile_enable.argtypes = [C.c_int32]
         L.gsr_profile_reset.restype = None

@@ -253,20 +253,30 @@ class GaussianModel:
                 out[group["name"]] = group["params"][0]
         return out
 
-    def _prune_optimizer(self, mask):
-        out = {}
-        for group in self.optimizer.param_groups:
-            stored = self.optimizer.state.get(group["params"][0], None)
-            if stored is not None:
-                stored["exp_avg"] = stored["exp_avg"][mask]
-                stored["exp_avg_sq"] = stored["exp_avg_sq"][mask]
-                del self.optimizer.state[group["params"][0]]
-                group["params"][0] = nn.Parameter(group["params"][0][mask].requires_grad_(True))
-                self.optimizer.state[group["params"][0]] = stored
-            else:
-                group["params"][0] = nn.Parameter(group["params"][0][mask].requires_grad_(True))
-            out[group["name"]] = group["params"][0]
-        return out
+    def _prune_optimizer(self, mask, extra=()):
+        """Keeps the rows of `mask` in every parameter, its Adam moments and the `extra` per-Gaussian tensors with ONE
+        fused compaction (compaction.py) instead of ~21 boolean-index operations; returns (params by name, extras)."""
+        from .compaction import compact_rows
+        groups = self.optimizer.param_groups
+        olds = [g["params"][0] for g in groups]
+        states = [self.optimizer.state.get(p, None) for p in olds]
+        batch = [p.detach() for p in olds]
+        for st in states:
+            if st is not None:
+                batch += [st["exp_avg"], st["exp_avg_sq"]]
+        batch += list(extra)
+        new = compact_rows(batch, mask)
+        out, k = {}, len(olds)
+        for i, (group, old, st) in enumerate(zip(groups, olds, states)):
+            new_p = nn.Parameter(new[i].requires_grad_(True))
+            if st is not None:
+                st["exp_avg"], st["exp_avg_sq"] = new[k], new[k + 1]
+                k += 2
+                del self.optimizer.state[old]
+                self.optimizer.state[new_p] = st
+            group["params"][0] = new_p
+            out[group["name"]] = new_p
+        return out, new[k:]
 
     def _adopt(self, t):
         self._xyz, self._features_dc, self._features_rest = t["xyz"], t["f_dc"], t["f_rest"]
@@ -274,11 +284,9 @@ class GaussianModel:
 
     def prune_points(self, mask):
         keep = ~mask
-        self._adopt(self._prune_optimizer(keep))
-        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
-        self.denom = self.denom[keep]
-        self.max_radii2D = self.max_radii2D[keep]
-        self._segments = self._segments[keep]
+        params, extras = self._prune_optimizer(keep, (self.xyz_gradient_accum, self.denom, self.max_radii2D, self._segments))
+        self._adopt(params)
+        self.xyz_gradient_accum, self.denom, self.max_radii2D, self._segments = extras
 
     def cat_tensors_to_optimizer(self, tensors_dict):
         out = {}

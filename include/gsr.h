@@ -209,6 +209,19 @@ int32_t gsr_adam_step(int32_t count, float* const* params, const float* const* g
                       const float* step_size, const float* inv_bc2_sqrt, double beta1, double beta2,
                       double eps, gsr_stream_t stream);
 
+/* Row compaction of the per-Gaussian tensors (pruning, scene/gaussian_model.py:398-470: `tensor[mask]` for the six
+ * parameters, their Adam moments and the densification statistics).  Two calls:
+ *   gsr_compact_plan  : exclusive scan of the device bool mask `keep` [n_rows] into workspace memory;
+ *                       *offsets_out (device u32 [n_rows + 1], inside `ws`) maps row -> new row, its last entry is
+ *                       the number of rows kept -- the caller reads it to size the destination tensors;
+ *   gsr_compact_apply : ONE launch moving up to 24 tensors (row sizes multiples of 4 bytes, host arrays of device
+ *                       pointers) from src[i] to dst[i]. */
+size_t gsr_compact_workspace_bytes(int64_t n_rows);
+int32_t gsr_compact_plan(const uint8_t* keep, int64_t n_rows, void* ws, size_t ws_bytes,
+                         const uint32_t** offsets_out, gsr_stream_t stream);
+int32_t gsr_compact_apply(int32_t count, const void* const* src, void* const* dst, const int32_t* row_bytes,
+                          int64_t n_rows, const uint8_t* keep, const uint32_t* offsets, gsr_stream_t stream);
+
 /* Opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline figures).
  * `mask`: bit k enables kernel k in the order of the names below (-1 = all, 0 = off); timing only
  * the few big kernels keeps the event overhead out of the measured step.
