@@ -139,13 +139,33 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_hist_kernel(const uint32_t* __res
     for (int i = threadIdx.x; i < nbins; i += RS_BLOCK) table[(size_t)i * nblocks + blockIdx.x] = hist[i];
 }
 
+// Per digit (one workgroup each): exclusive prefix of the digit's counts over the tiles, in place, plus the digit total.
+// The table is digit-major, so a workgroup reads one contiguous row.  Together with the 256-value scan of the totals
+// that every scatter workgroup does for itself, this replaces a generic two-launch scan of the whole table.
+__global__ void __launch_bounds__(RS_BLOCK) rs_digit_scan_kernel(uint32_t* __restrict__ table, int nblocks,
+                                                                 uint32_t* __restrict__ digit_total) {
+    __shared__ uint32_t wt[RS_WAVES];
+    uint32_t* row = table + (size_t)blockIdx.x * nblocks;
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += RS_BLOCK) {
+        const int j = base + threadIdx.x;
+        const uint32_t v = j < nblocks ? row[j] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(v, total, wt);
+        if (j < nblocks) row[j] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
+}
+
 template <int BITS>
 __global__ void __launch_bounds__(RS_BLOCK) rs_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                               const uint32_t* __restrict__ vals_in,
                                                               uint32_t* __restrict__ keys_out,
                                                               uint32_t* __restrict__ vals_out, int64_t n,
                                                               int shift, int nblocks,
-                                                              const uint32_t* __restrict__ table_scanned) {
+                                                              const uint32_t* __restrict__ table_scanned,
+                                                              const uint32_t* __restrict__ digit_total) {
     constexpr int NB = 1 << BITS;
     constexpr uint32_t MASK = NB - 1;
     __shared__ uint32_t wave_hist[RS_WAVES][NB];
@@ -157,7 +177,12 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_scatter_kernel(const uint32_t* __
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < RS_WAVES * NB; i += RS_BLOCK) (&wave_hist[0][0])[i] = 0;
-    for (int i = tid; i < NB; i += RS_BLOCK) gbase[i] = table_scanned[(size_t)i * nblocks + blockIdx.x];
+    __syncthreads();
+    {   // global base of (digit, this tile) = first output index of the digit + the digit's count in earlier tiles
+        uint32_t tot_unused;
+        const uint32_t dbase = block_excl_scan(tid < NB ? digit_total[tid] : 0u, tot_unused, wt);
+        if (tid < NB) gbase[tid] = dbase + table_scanned[(size_t)tid * nblocks + blockIdx.x];
+    }
     __syncthreads();
 
     const int64_t block_base = (int64_t)blockIdx.x * RS_TILE;
@@ -248,9 +273,9 @@ static size_t rs_table_entries(int64_t n) {
 }
 
 size_t gsr_sort_ws_bytes(int64_t n) {
-    // table (raw) + table (scanned, +1 for the total) + scan partials
+    // table (raw, scanned in place per digit) + digit totals
     const size_t e = rs_table_entries(n);
-    return gsr_align(e * 4) + gsr_align((e + 1) * 4) + gsr_scan_workspace_bytes((int64_t)e);
+    return gsr_align(e * 4) + gsr_align(RS_MAX_BINS * 4);
 }
 
 int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
@@ -269,8 +294,7 @@ int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint3
     const int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
     const size_t e = rs_table_entries(n);
     uint32_t* table = static_cast<uint32_t*>(ws);
-    uint32_t* scanned = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + gsr_align(e * 4));
-    void* scan_ws = static_cast<char*>(ws) + gsr_align(e * 4) + gsr_align((e + 1) * 4);
+    uint32_t* digit_total = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + gsr_align(e * 4));
 
     // ping-pong so that the last pass lands in *_out
     const uint32_t* src_k = keys_in; const uint32_t* src_v = vals_in;
@@ -288,12 +312,14 @@ int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint3
             hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_BLOCK), 0, s, src_k, n, bit,
                                (uint32_t)(nbins - 1), nbins, nblocks, table);
         }
-        int rc = gsr_exclusive_scan_u32(table, nullptr, scanned, (int64_t)nbins * nblocks, scan_ws, s);
-        if (rc != GSR_OK) return rc;
+        {
+            GsrProfileScope prof(GSR_K_SCAN, s);
+            hipLaunchKernelGGL(rs_digit_scan_kernel, dim3(nbins), dim3(RS_BLOCK), 0, s, table, nblocks, digit_total);
+        }
         {
             GsrProfileScope prof(GSR_K_SORT_SCATTER, s);
 #define RS_CASE(B) case B: hipLaunchKernelGGL(rs_scatter_kernel<B>, dim3(nblocks), dim3(RS_BLOCK), 0, s, \
-                                              src_k, src_v, dst_k, dst_v, n, bit, nblocks, scanned); break;
+                                              src_k, src_v, dst_k, dst_v, n, bit, nblocks, table, digit_total); break;
             switch (w) { RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
                 default: gsr_set_error("radix digit width %d", w); return GSR_E_INVALID; }
 #undef RS_CASE
