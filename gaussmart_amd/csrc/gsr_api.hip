@@ -312,6 +312,10 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     //   * when the bound is huge (> GSR_EXACT_ROWS_BYTES, default 8 GiB: tens of millions of instances) R is read
     //     back first -- one host wait in the backward -- and the buffer is sized exactly (R is ~2.6 D in practice).
     const size_t n_inst = size_t(num_rendered > 0 ? num_rendered : 1);
+    if (n_inst * GSR_SUBROWS > 0xFFFFFFFFull) {   // slot indices are u32
+        gsr_set_error("%zu instances: gradient-row slots would overflow 32 bits", n_inst);
+        return GSR_E_UNSUPPORTED;
+    }
     const bool wide = view->channels != 3;
     const size_t row_bytes_each = size_t(GSR_GROW_FLOATS) * 4 + (wide ? size_t(view->channels) * 4 : 0);
     const size_t cnt_bytes = gsr_align(n_inst * 4);
