@@ -257,6 +257,8 @@ def main():
                          "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, same scene; "
                                            "2 x FETCH_SIZE + WRITE_SIZE)",
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per_kernel[dom]},
+            "hbm_peak_gb": {"allocated": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
+                            "reserved": round(torch.cuda.max_memory_reserved(dev) / 2**30, 2)},
             "reference_iter_time_ms": ref_iter_ms,    # median of the reference's fwd+loss+bwd bracket (no Adam)
             "kernel_ms": {k: round(v, 4) for k, v in per_kernel.items()},
             "kernel_ms_warmup": {k: round(v, 4) for k, v in warm.items()},
