@@ -47,7 +47,7 @@
 #define RB_ROW GSR_GROW_FLOATS   // 20 floats
 
 struct RenderBwdParams {
-    int W, H, gx;
+    int W, H, gx, n_tiles, per_xcd;
     uint32_t flags;
     const uint32_t* ranges; const uint32_t* inst_row;
     const float4* splat; const uint32_t* touch; const uint32_t* slot_off; const float* bg;
@@ -74,7 +74,12 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
     const int lane = tid & 63, wave = tid >> 6;
     float4* s_rec = s_rec_all[wave];
     float4* s_feat = s_feat_all[STAGE_FEAT ? wave : 0];
-    const int tile_x = blockIdx.x, tile_y = blockIdx.y;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b
+    // takes tile (b % 8) * per_xcd + b / 8 -- every XCD owns one contiguous band of tiles, and the records shared by
+    // neighbouring tiles are fetched into ONE L2 instead of several
+    const int tile_lin = (int)(blockIdx.x & 7u) * p.per_xcd + (int)(blockIdx.x >> 3);
+    if (tile_lin >= p.n_tiles) return;
+    const int tile_y = tile_lin / p.gx, tile_x = tile_lin - tile_y * p.gx;
     const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
     const int grp = lane >> 4, l16 = lane & 15;   // DPP row = 4x4 pixel block, same mapping as render_fwd
     const uint32_t below_mask = ((1u << (8 * wave + grp)) - 1u) & 0x0F0F0F0Fu;   // touch bits of the blocks before mine
@@ -410,7 +415,8 @@ int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32
     p.feat = feat; p.point_list = point_list; p.feat_rows = feat_rows; p.C = v.channels;
     if (p.gx <= 0 || gy <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_RENDER_BWD, s);
-    const dim3 grid(p.gx, gy), block(RB_BLOCK);
+    p.n_tiles = p.gx * gy; p.per_xcd = (p.n_tiles + 7) / 8;
+    const dim3 grid(8 * p.per_xcd), block(RB_BLOCK);
     if (feat == nullptr) {
         hipLaunchKernelGGL(render_bwd_kernel<0>, grid, block, 0, s, p);
     } else {

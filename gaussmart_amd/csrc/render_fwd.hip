@@ -36,7 +36,7 @@
 #define RF_WAVES 4
 
 struct RenderFwdParams {
-    int W, H, gx;
+    int W, H, gx, n_tiles, per_xcd;
     uint32_t flags;
     const uint32_t* ranges; const float4* splat;   // splat table [N] x 5 float4, gathered by id
     const float* bg;
@@ -70,7 +70,12 @@ __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : 2) rend
     const int lane = tid & 63, wave = tid >> 6;
     float4* s_rec = s_rec_all[wave];
     float4* s_feat = s_feat_all[STAGE_FEAT ? wave : 0];
-    const int tile_x = blockIdx.x, tile_y = blockIdx.y;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b
+    // takes tile (b % 8) * per_xcd + b / 8 -- every XCD owns one contiguous band of tiles, and the records shared by
+    // neighbouring tiles are fetched into ONE L2 instead of several
+    const int tile_lin = (int)(blockIdx.x & 7u) * p.per_xcd + (int)(blockIdx.x >> 3);
+    if (tile_lin >= p.n_tiles) return;
+    const int tile_y = tile_lin / p.gx, tile_x = tile_lin - tile_y * p.gx;
     const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
     // lanes 16g..16g+15 (one DPP row) own the 4x4 pixel block g of the quad: the backward walks per-block lists
     const int grp = lane >> 4, l16 = lane & 15;
@@ -254,7 +259,8 @@ int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float*
     p.touch = touch; p.feat = feat; p.point_list = point_list; p.C = v.channels;
     if (p.gx <= 0 || gy <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_RENDER_FWD, s);
-    const dim3 grid(p.gx, gy), block(RF_BLOCK);
+    p.n_tiles = p.gx * gy; p.per_xcd = (p.n_tiles + 7) / 8;
+    const dim3 grid(8 * p.per_xcd), block(RF_BLOCK);
     if (feat == nullptr) {
         hipLaunchKernelGGL(render_fwd_kernel<0>, grid, block, 0, s, p);
     } else {
