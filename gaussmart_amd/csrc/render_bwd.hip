@@ -198,25 +198,22 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
 
         // only the splats the forward blended into >= 1 pixel of a block carry any gradient there: one to-do
         // mask per 4x4 block (= DPP row), held by all 16 lanes of the row
-        uint32_t todo_lo, todo_hi;
+        // (the four masks live in SGPRs: picking and clearing bits is scalar work, the vector unit only selects)
+        unsigned long long m0, m1, m2, m3;
         {
             const uint32_t t = lane < nb ? (touch_of_lane >> (8 * wave)) & 0xFu : 0u;
-            const unsigned long long m0 = __ballot((t & 1u) != 0), m1 = __ballot((t & 2u) != 0);
-            const unsigned long long m2 = __ballot((t & 4u) != 0), m3 = __ballot((t & 8u) != 0);
-            const unsigned long long mm = grp == 0 ? m0 : grp == 1 ? m1 : grp == 2 ? m2 : m3;
-            todo_lo = (uint32_t)mm; todo_hi = (uint32_t)(mm >> 32);
+            m0 = __ballot((t & 1u) != 0); m1 = __ballot((t & 2u) != 0);
+            m2 = __ballot((t & 4u) != 0); m3 = __ballot((t & 8u) != 0);
         }
-        while (true) {
-            const bool has = (todo_lo | todo_hi) != 0u;
-            if (!__any(has)) break;
-            // deepest entry of this block's mask first
-            const bool in_hi = todo_hi != 0u;
-            const uint32_t word = in_hi ? todo_hi : todo_lo;
-            const int bitpos = 31 - __clz((int)word);                 // -1 when the row has nothing left
-            const uint32_t clr = has ? ~(1u << (bitpos & 31)) : 0xFFFFFFFFu;
-            todo_hi &= in_hi ? clr : 0xFFFFFFFFu;
-            todo_lo &= in_hi ? 0xFFFFFFFFu : clr;
-            const int j = has ? bitpos + (in_hi ? 32 : 0) : 0;
+        while ((m0 | m1 | m2 | m3) != 0ull) {
+            // deepest entry of each block's mask first
+            const int j0 = m0 ? 63 - __builtin_clzll(m0) : -1, j1 = m1 ? 63 - __builtin_clzll(m1) : -1;
+            const int j2 = m2 ? 63 - __builtin_clzll(m2) : -1, j3 = m3 ? 63 - __builtin_clzll(m3) : -1;
+            m0 &= ~(1ull << (j0 & 63)); m1 &= ~(1ull << (j1 & 63));      // (an empty mask stays empty)
+            m2 &= ~(1ull << (j2 & 63)); m3 &= ~(1ull << (j3 & 63));
+            const int jr = grp == 0 ? j0 : grp == 1 ? j1 : grp == 2 ? j2 : j3;
+            const bool has = jr >= 0;
+            const int j = max(jr, 0);
             const int cidx = lo + j;                            // 0-based position in the tile list
             const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
             const float4 a3 = s_rec[j * 5 + 3];
