@@ -142,6 +142,8 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
             if (k < p.C) bg_dot_dpixel += p.bg[k] * dL_dpixf[k];
     }
 
+    const bool quad_has_dist = __any(dL_dreg != 0.f), quad_has_median = __any(dL_dmedian != 0.f);   // wave-uniform
+
     // running state of the back-to-front recursion
     float T = T_final;
     float last_alpha = 0.f, last_q = 0.f, acc_q = 0.f, last_dL_dT = 0.f;
@@ -266,15 +268,19 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
                 gc0 = w * dL_dpix0; gc1 = w * dL_dpix1; gc2 = w * dL_dpix2;
                 gn0 = w * dL_dn0; gn1 = w * dL_dn1; gn2 = w * dL_dn2;
 
-                // distortion, median depth
-                float dmd_dd;
-                const float m_d = gsr_depth_map(c_d, dmd_dd);
+                // median depth and distortion: skipped (wave-uniformly) when the whole quad receives no gradient on that
+                // channel -- the reference's defaults (depth_ratio = 0, lambda_dist = 0) make both identically zero, and
+                // every term below is a multiple of it
                 float dL_dz = w * dL_ddepth;
-                if (active && cidx == median_contributor - 1) dL_dz += dL_dmedian;
-                const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
-                dL_dalpha += dL_dweight - last_dL_dT;
-                last_dL_dT = dL_dweight * alpha + one_m_alpha * last_dL_dT;
-                dL_dz += 2.0f * w * (m_d * final_A - final_D) * dL_dreg * dmd_dd;
+                if (quad_has_median && active && cidx == median_contributor - 1) dL_dz += dL_dmedian;
+                if (quad_has_dist) {
+                    float dmd_dd;
+                    const float m_d = gsr_depth_map(c_d, dmd_dd);
+                    const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
+                    dL_dalpha += dL_dweight - last_dL_dT;
+                    last_dL_dT = dL_dweight * alpha + one_m_alpha * last_dL_dT;
+                    dL_dz += 2.0f * w * (m_d * final_A - final_D) * dL_dreg * dmd_dd;
+                }
 
                 dL_dalpha *= T;
                 last_alpha = alpha;
