@@ -47,6 +47,17 @@ def _f32c(t, name, device):
 
 
 _PLACEHOLDER = {}
+_ZERO_IMAGES = {}
+
+
+def _zero_image(channels, H, W, device):
+    """Read-only zero gradient image for an output nobody differentiated (e.g. allmap before the regularizers
+    switch on): cached per shape, so the backward does not fill 58 MB every step."""
+    key = (int(channels), int(H), int(W), torch.device(device))
+    z = _ZERO_IMAGES.get(key)
+    if z is None:
+        z = _ZERO_IMAGES[key] = torch.zeros((channels, H, W), dtype=torch.float32, device=device)
+    return z
 
 
 def _ptr(t):
@@ -202,6 +213,7 @@ def wait_pending_params(device):
 def release_workspace():
     """Drop every cached library buffer (e.g. before handing the GPU to something else)."""
     _POOL.clear()
+    _ZERO_IMAGES.clear()
 
 
 def _make_view(rs: GaussianRasterizationSettings, sh_coeffs: int, flags: int, device, channels: int = 3, keep=None):
@@ -305,9 +317,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         N = means3D.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
         grad_color = _f32c(grad_color, "grad_color", device) if grad_color is not None else \
-            torch.zeros((ctx.channels, H, W), device=device)
+            _zero_image(ctx.channels, H, W, device)
         grad_allmap = _f32c(grad_allmap, "grad_allmap", device) if grad_allmap is not None else \
-            torch.zeros((7, H, W), device=device)
+            _zero_image(7, H, W, device)
 
         with torch.cuda.device(device):
             view, keep = _make_view(rs, sh.shape[1] if sh is not None else 0, ctx.flags, device, ctx.channels, ctx.view_keep)
@@ -402,8 +414,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         device = xyz.device
         N = xyz.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
-        grad_color = _f32c(grad_color, "grad_color", device) if grad_color is not None else torch.zeros((3, H, W), device=device)
-        grad_allmap = _f32c(grad_allmap, "grad_allmap", device) if grad_allmap is not None else torch.zeros((7, H, W), device=device)
+        grad_color = _f32c(grad_color, "grad_color", device) if grad_color is not None else _zero_image(3, H, W, device)
+        grad_allmap = _f32c(grad_allmap, "grad_allmap", device) if grad_allmap is not None else _zero_image(7, H, W, device)
         rest = f_rest if f_rest.shape[1] > 0 else None
         with torch.cuda.device(device):
             view, keep = _make_view(rs, ctx.M, ctx.flags, device, 3, ctx.view_keep)
