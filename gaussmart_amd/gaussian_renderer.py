@@ -61,6 +61,22 @@ def depth_to_normal(view, depth):
     return output
 
 
+_ZERO_POINTS = {}
+
+
+def _zero_leaf(xyz):
+    """A fresh autograd leaf of zeros shaped like xyz.  Nothing ever reads or writes its VALUES (the rasterizer only
+    fills its .grad), so on a HIP device all leaves alias one cached zero buffer instead of being filled every call."""
+    if not xyz.is_cuda:
+        return torch.zeros_like(xyz, requires_grad=True)
+    key = (tuple(xyz.shape), xyz.dtype, xyz.device)
+    z = _ZERO_POINTS.get(key)
+    if z is None:
+        _ZERO_POINTS.clear()          # one shape at a time (N changes with densification)
+        z = _ZERO_POINTS[key] = torch.zeros(xyz.shape, dtype=xyz.dtype, device=xyz.device)
+    return z.detach().requires_grad_(True)
+
+
 def _use_raw_path(pc, pipe, override_color, xyz):
     """Opt-in (pipe.fused_activations) fast path: only when the model exposes the raw parameter
     tensors with the reference's activations (exp / sigmoid / normalize) and nothing is overridden."""
@@ -81,7 +97,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     device = xyz.device
     # the reference adds 0 and calls retain_grad() (gaussian_renderer/__init__.py:27-31); a leaf that requires
     # grad receives the same .grad without the extra add and the gradient clone of retain_grad
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=device)
+    screenspace_points = _zero_leaf(xyz)
 
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
