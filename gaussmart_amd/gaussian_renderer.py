@@ -61,6 +61,20 @@ def depth_to_normal(view, depth):
     return output
 
 
+class _LazyRenderPkg(dict):
+    def __missing__(self, key):
+        if key == "visibility_filter":
+            self[key] = self["radii"] > 0
+            return self[key]
+        raise KeyError(key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+
 _ZERO_POINTS = {}
 
 
@@ -147,10 +161,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
             scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
 
+    if not surface_maps:
+        # fused-objective path: "visibility_filter" (radii > 0) is computed on first access instead of every call
+        return _LazyRenderPkg({"render": rendered_image, "viewspace_points": means2D, "radii": radii, "allmap": allmap})
     rets = {"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii,
             "allmap": allmap}
-    if not surface_maps:
-        return rets
 
     render_alpha = allmap[1:2]
     # view-space normals -> world space
