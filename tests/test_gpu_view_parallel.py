@@ -25,7 +25,10 @@ def nccl_world1(gpu_device):
         return
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu_device)
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu_device)
+    except Exception as e:      # no usable bootstrap interface on this box: the collectives cannot be rehearsed here
+        pytest.skip(f"RCCL process group of size 1 could not be created: {e}")
     yield
     dist.destroy_process_group()
 
