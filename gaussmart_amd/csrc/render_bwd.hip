@@ -143,6 +143,7 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
     }
 
     const bool quad_has_dist = __any(dL_dreg != 0.f), quad_has_median = __any(dL_dmedian != 0.f);   // wave-uniform
+    const bool quad_has_surf = __any(dL_ddepth != 0.f || dL_daccum != 0.f || dL_dn0 != 0.f || dL_dn1 != 0.f || dL_dn2 != 0.f);
 
     // running state of the back-to-front recursion
     float T = T_final;
@@ -245,10 +246,11 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
                 //   q_i = c_i . dL/dC + z_i dL/dD + 1 dL/dA + n_i . dL/dN
                 const float c0 = a3.w, c1 = a4.x, c2 = a4.y;
                 const float n0 = a2.w, n1 = a3.x, n2 = a3.y;
-                float q = c_d * dL_ddepth + dL_daccum + n0 * dL_dn0 + n1 * dL_dn1 + n2 * dL_dn2;
+                // (the surface channels -- depth, alpha, normal -- carry no gradient before the regularizers switch on)
+                float q = 0.f;
+                if (quad_has_surf) q = c_d * dL_ddepth + dL_daccum + n0 * dL_dn0 + n1 * dL_dn1 + n2 * dL_dn2;
                 if (FEAT16 == 0) {
-                    q = c0 * dL_dpix0 + c1 * dL_dpix1 + c2 * dL_dpix2 + c_d * dL_ddepth + dL_daccum
-                      + n0 * dL_dn0 + n1 * dL_dn1 + n2 * dL_dn2;
+                    q += c0 * dL_dpix0 + c1 * dL_dpix1 + c2 * dL_dpix2;
                 } else {
                     const float4* f = STAGE_FEAT ? s_feat + j * NQ      // per-row LDS address
                                                  : reinterpret_cast<const float4*>(p.feat + (size_t)gid * p.C);
@@ -266,7 +268,8 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
                 last_q = q;
                 float dL_dalpha = q - acc_q;
                 gc0 = w * dL_dpix0; gc1 = w * dL_dpix1; gc2 = w * dL_dpix2;
-                gn0 = w * dL_dn0; gn1 = w * dL_dn1; gn2 = w * dL_dn2;
+                gn0 = 0.f; gn1 = 0.f; gn2 = 0.f;
+                if (quad_has_surf) { gn0 = w * dL_dn0; gn1 = w * dL_dn1; gn2 = w * dL_dn2; }
 
                 // median depth and distortion: skipped (wave-uniformly) when the whole quad receives no gradient on that
                 // channel -- the reference's defaults (depth_ratio = 0, lambda_dist = 0) make both identically zero, and
