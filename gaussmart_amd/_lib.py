@@ -18,12 +18,13 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgsr_hip.so")
 ABI_VERSION = 2
 
 GSR_BUF_GEOM, GSR_BUF_BINNING, GSR_BUF_IMAGE, GSR_BUF_SCRATCH, GSR_BUF_SCRATCH2 = range(5)
+GSR_BUF_SYNC_SH = 100     # not a buffer: "the SH colour pass is about to be enqueued" (GSR_FLAG_DEFER_COLOR)
 GSR_FLAG_CLAMP_PASSTHROUGH = 1
 GSR_FLAG_FILTER_DEPTH_GRAD = 2
 GSR_FLAGS_UPSTREAM = 3
 GSR_FLAG_DEBUG_NO_CULL = 4
 GSR_FLAG_RAW_PARAMS = 8
-GSR_FLAG_COLOR_AFTER_ALLOC = 16
+GSR_FLAG_DEFER_COLOR = 16
 
 KERNEL_NAMES = ("preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
                 "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "loss_fwd", "loss_bwd",

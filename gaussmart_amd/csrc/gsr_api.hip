@@ -208,7 +208,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     void* sort_ws = scratch + 4 * nb;
     void* scan_ws = static_cast<char*>(sort_ws) + sort_ws_n;
 
-    const bool color_after_alloc = (view->flags & (uint32_t)GSR_FLAG_COLOR_AFTER_ALLOC) != 0;
+    const bool defer_color = (view->flags & (uint32_t)GSR_FLAG_DEFER_COLOR) != 0;
     uint32_t D = 0;
     if (N > 0) {
         rc = gsr_launch_preprocess_fwd(*view, *g, splat, clamped, tiles_touched, tile_rect, depth_key, out->radii, s);
@@ -231,7 +231,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         GSR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         hipError_t e1 = hipMemcpyAsync(d_host, offs + N, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         hipError_t e2 = e1 == hipSuccess ? hipEventRecord(ev, s) : e1;
-        if (!color_after_alloc)
+        if (!defer_color)
             rc = e2 == hipSuccess ? gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, s) : GSR_OK;
         hipError_t e3 = e2 == hipSuccess ? hipEventSynchronize(ev) : e2;   // the one host wait of the forward
         (void)hipEventDestroy(ev);
@@ -245,10 +245,6 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     const GsrBinLayout BL(D, n_tiles);
     void* binning = alloc(ctx, GSR_BUF_BINNING, BL.total);
     if (!binning) { gsr_set_error("allocator returned NULL (binning)"); return GSR_E_ALLOC; }
-    if (color_after_alloc && N > 0) {   // the caller may have enqueued a stream wait inside the callback above
-        rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, s);
-        if (rc != GSR_OK) return rc;
-    }
     out->binning = binning;
     uint32_t* point_list = at<uint32_t>(binning, BL.point_list);
     uint32_t* inst_row = at<uint32_t>(binning, BL.inst_row);
@@ -278,6 +274,11 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
     }
 
+    if (defer_color && N > 0) {   // binning did not need the colours: announce the pass, then enqueue it
+        if (!alloc(ctx, GSR_BUF_SYNC_SH, 0)) { gsr_set_error("allocator refused GSR_BUF_SYNC_SH"); return GSR_E_ALLOC; }
+        rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, s);
+        if (rc != GSR_OK) return rc;
+    }
     return gsr_launch_render_fwd(*view, ranges, splat, at<float>(image, IL.final_T),
                                  at<uint32_t>(image, IL.n_contrib), out->out_color, out->out_allmap,
                                  at<uint8_t>(binning, BL.touch), view->channels == 3 ? nullptr : g->colors_precomp,

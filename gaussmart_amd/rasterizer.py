@@ -142,11 +142,11 @@ class _Lease:
 class _Allocator:
     """Adapter between gsr_alloc_fn and the pool for ONE library call."""
 
-    def __init__(self, device, before_binning=None):
+    def __init__(self, device, before_color=None):
         self.device = device
         self.buffers = {}
         self.error = None
-        self.before_binning = before_binning    # called once, right before the BINNING buffer is handed out
+        self.before_color = before_color        # called once, when the library announces the SH colour pass
         self.stream = torch.cuda.current_stream(device).cuda_stream
         self.kept = _Lease()        # geom / binning / image: travel with the autograd node
         self.scratch = _Lease()     # released by done()
@@ -155,9 +155,11 @@ class _Allocator:
     def _alloc(self, _ctx, which, nbytes):
         try:
             which, nbytes = int(which), max(int(nbytes), 1)
-            if which == _lib.GSR_BUF_BINNING and self.before_binning is not None:
-                hook, self.before_binning = self.before_binning, None
-                hook()
+            if which == _lib.GSR_BUF_SYNC_SH:        # notification, not an allocation
+                if self.before_color is not None:
+                    hook, self.before_color = self.before_color, None
+                    hook()
+                return 1
             key = (self.device, self.stream, which)
             t = _POOL.take(key, nbytes, self.device)
             lease = self.scratch if which in (_lib.GSR_BUF_SCRATCH, _lib.GSR_BUF_SCRATCH2) else self.kept
@@ -195,7 +197,8 @@ def _finish_lease(ctx):
 # Pipelined data-parallel step (view_parallel.py): the SH parameters may still be receiving their Adam update on a
 # side stream when the next forward starts.  The event that marks the end of that update is parked here; the raw
 # forward lets its geometry / binning phase run and makes the stream wait right before the SH colour pass
-# (GSR_FLAG_COLOR_AFTER_ALLOC); every other consumer waits up front.
+# (GSR_FLAG_DEFER_COLOR: the pass is enqueued after binning, announced through the allocator); every other consumer
+# waits up front.
 _PENDING_PARAM_EVENT = {}
 
 
@@ -374,7 +377,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         pending = _PENDING_PARAM_EVENT.pop(torch.device(device), None)
         hook = None
         if pending is not None:
-            flags |= _lib.GSR_FLAG_COLOR_AFTER_ALLOC
+            flags |= _lib.GSR_FLAG_DEFER_COLOR
             hook = lambda: torch.cuda.current_stream(device).wait_event(pending)
         rest = f_rest if f_rest.shape[1] > 0 else None
         with torch.cuda.device(device):
@@ -385,17 +388,17 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             allmap = torch.empty((7, H, W), dtype=torch.float32, device=device)
             radii = torch.empty((N,), dtype=torch.int32, device=device)
             out = _lib.GsrForwardOut(color.data_ptr(), allmap.data_ptr(), radii.data_ptr(), 0, None, None, None)
-            alloc = _Allocator(device, before_binning=hook)
+            alloc = _Allocator(device, before_color=hook)
             stream = torch.cuda.current_stream(device).cuda_stream
             rc = L.gsr_forward(C.byref(view), C.byref(g), C.byref(out), alloc.cb, None, C.c_void_p(stream))
             alloc.done()
-            if alloc.before_binning is not None:     # the library returned before asking for the binning buffer
-                alloc.before_binning()
+            if alloc.before_color is not None:       # the library returned before announcing the colour pass
+                alloc.before_color()
             if rc != 0 and alloc.error is not None:
                 raise alloc.error
             _lib.check(rc)
         ctx.lease = alloc.kept
-        ctx.raster_settings, ctx.flags, ctx.num_rendered, ctx.M = rs, flags & ~_lib.GSR_FLAG_COLOR_AFTER_ALLOC, int(out.num_rendered), M
+        ctx.raster_settings, ctx.flags, ctx.num_rendered, ctx.M = rs, flags & ~_lib.GSR_FLAG_DEFER_COLOR, int(out.num_rendered), M
         ctx.view_keep = keep
         ctx.set_materialize_grads(False)     # no zero tensors for the unused radii / image gradients
         ctx.save_for_backward(xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, radii,

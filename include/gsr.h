@@ -51,11 +51,11 @@ enum {
     GSR_FLAG_FILTER_DEPTH_GRAD = 2, /* low-pass branch: dL/dz also added to dL/dTw.x,.y times s   */
     GSR_FLAGS_UPSTREAM = 3,
     GSR_FLAG_DEBUG_NO_CULL = 4,     /* test aid: ignore the per-wave cull rect (results are bit-identical) */
-    GSR_FLAG_COLOR_AFTER_ALLOC = 16, /* enqueue the SH colour pass AFTER the GSR_BUF_BINNING allocation callback
-                                        instead of before the instance-count read-back: the caller may make the
-                                        stream wait there for SH parameters that are still being updated on
-                                        another stream (pipelined data-parallel step); geometry inputs (means,
-                                        scales, rotations, opacities) must be final when gsr_forward is called */
+    GSR_FLAG_DEFER_COLOR = 16,      /* enqueue the SH colour pass as LATE as possible -- after binning, right before the
+                                       compositing -- and announce it through the allocator (GSR_BUF_SYNC_SH): the caller
+                                       may make the stream wait there for SH parameters that are still being updated on
+                                       another stream (pipelined data-parallel step); the geometry inputs (means, scales,
+                                       rotations, opacities) must be final when gsr_forward is called */
     GSR_FLAG_RAW_PARAMS = 8         /* opacities are logits, scales are log-scales, rotations un-normalised:
                                        the activations of scene/gaussian_model.py:37-43 (sigmoid, exp,
                                        normalize) run inside the kernels and the gradients returned are
@@ -99,7 +99,11 @@ typedef struct GsrGaussians {
  * the backward has run.  GSR_BUF_SCRATCH may be released as soon as the call returns
  * (stream-ordered). */
 enum { GSR_BUF_GEOM = 0, GSR_BUF_BINNING = 1, GSR_BUF_IMAGE = 2, GSR_BUF_SCRATCH = 3,
-       GSR_BUF_SCRATCH2 = 4, GSR_BUF_COUNT = 5 };
+       GSR_BUF_SCRATCH2 = 4, GSR_BUF_COUNT = 5,
+       /* not a buffer: with GSR_FLAG_DEFER_COLOR the allocator is called once with this kind and 0 bytes right before
+          the SH colour pass is enqueued (the last moment the SH parameters may still be in flight on another
+          stream: the callback may enqueue a stream wait); any non-NULL return value means "go on" */
+       GSR_BUF_SYNC_SH = 100 };
 
 /* Must return device memory of >= bytes, 256-byte aligned, or NULL. */
 typedef void* (*gsr_alloc_fn)(void* ctx, int32_t which, size_t bytes);

@@ -1,5 +1,5 @@
 """Pipelined data-parallel step on one GPU (RCCL group of size 1, `force=True`): the collectives, the side
-stream, the deferred SH colour pass (GSR_FLAG_COLOR_AFTER_ALLOC) and the flat gradient buffer are all exercised;
+stream, the deferred SH colour pass (GSR_FLAG_DEFER_COLOR) and the flat gradient buffer are all exercised;
 with one rank the averaged gradient is the gradient itself, so the parameters after a few steps must equal those of
 the plain single-GPU step bit for bit."""
 import os
