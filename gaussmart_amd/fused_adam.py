@@ -58,3 +58,32 @@ class FusedAdam(torch.optim.Adam):
                         (C.c_float * n)(*[c[4] for c in chunk]), (C.c_float * n)(*[c[5] for c in chunk]),
                         beta1, beta2, eps, C.c_void_p(stream_h)))
         return loss
+
+    @torch.no_grad()
+    def step_slice(self, p, start, stop, stream=None, count_step=True):
+        """Adam update of the flat element range [start, stop) of ONE parameter (pipelined data-parallel step: a large
+        tensor is updated chunk by chunk as the chunks of its gradient arrive).  `count_step=False` for every chunk
+        after the first one of an iteration, so the step count advances once."""
+        L = _lib.lib()
+        group = next(g for g in self.param_groups if any(q is p for q in g["params"]))
+        if p.grad is None or stop <= start:
+            return
+        if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+            raise _lib.GsrError("FusedAdam needs contiguous float32 parameters and gradients on a HIP device")
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        if count_step:
+            st["step"] += 1
+        t = float(st["step"])
+        beta1, beta2 = group["betas"]
+        off = 4 * int(start)
+        ptr = lambda x: (C.c_void_p * 1)(x.data_ptr() + off)
+        with torch.cuda.device(p.device):
+            stream_h = (stream if stream is not None else torch.cuda.current_stream(p.device)).cuda_stream
+            _lib.check(L.gsr_adam_step(
+                1, ptr(p), ptr(p.grad), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), (C.c_int64 * 1)(int(stop - start)),
+                (C.c_float * 1)(group["lr"] / (1.0 - beta1 ** t)), (C.c_float * 1)(1.0 / math.sqrt(1.0 - beta2 ** t)),
+                beta1, beta2, group["eps"], C.c_void_p(stream_h)))

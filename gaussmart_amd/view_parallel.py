@@ -134,15 +134,23 @@ class ViewParallel:
         n_head = flat.numel() - rest_g.numel()
         head, tail = flat[:n_head], flat[n_head:]
         op = dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM
+        # the SH tail travels as two collectives, so that the Adam update of its first half overlaps the transfer of
+        # the second
+        n_tail = tail.numel()
+        cut = (n_tail // 2) & ~3                         # keep both halves 16-byte aligned
         w_head = dist.all_reduce(head, op=op, group=self.pg, async_op=True)
-        w_tail = dist.all_reduce(tail, op=op, group=self.pg, async_op=True)
+        w_t1 = dist.all_reduce(tail[:cut], op=op, group=self.pg, async_op=True) if cut > 0 else None
+        w_t2 = dist.all_reduce(tail[cut:], op=op, group=self.pg, async_op=True)
         w_head.wait()                                     # current stream waits for the first collective only
         optimizer.step(only=[p for p in params if p is not rest_p])
         if self._side is None:
             self._side = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(self._side):
-            w_tail.wait()
-            optimizer.step(only=[rest_p], stream=self._side)
+            if w_t1 is not None:
+                w_t1.wait()
+                optimizer.step_slice(rest_p, 0, cut, stream=self._side, count_step=True)
+            w_t2.wait()
+            optimizer.step_slice(rest_p, cut, n_tail, stream=self._side, count_step=w_t1 is None)
             ev = torch.cuda.Event()
             ev.record(self._side)
         flat.record_stream(self._side)                    # its memory may be reused only after the side stream is done
