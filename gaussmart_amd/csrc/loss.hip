@@ -163,6 +163,9 @@ __global__ void __launch_bounds__(256) loss_bwd_kernel(const float* __restrict__
         }
         __syncthreads();
         if (c + 1 < C) fetch(c + 1);
+        // this pixel's image / target values are only needed after both filter passes: request them now
+        float xv = 0.f, yv = 0.f;
+        if (inside) { const size_t o = (size_t)py * W + px; xv = img[c * HW + o]; yv = gt[c * HW + o]; }
         for (int i = threadIdx.x; i < LS_REG * LS_TILE; i += 256) {
             const int r = i / LS_TILE, q = i - r * LS_TILE;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -182,7 +185,6 @@ __global__ void __launch_bounds__(256) loss_bwd_kernel(const float* __restrict__
         }
         if (inside) {
             const size_t o = (size_t)py * W + px;
-            const float xv = img[c * HW + o], yv = gt[c * HW + o];
             const float d = xv - yv;
             const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
             dimg[c * HW + o] = k_ssim * (g0 + 2.f * xv * g1 + yv * g2) + k_l1 * sgn;
