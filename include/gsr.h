@@ -139,8 +139,8 @@ const char* gsr_last_error(void);
 int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrForwardOut* out,
                     gsr_alloc_fn alloc, void* alloc_ctx, gsr_stream_t stream);
 
-/* Backward: back-to-front replay per 8x8 pixel quad writing one gradient sub-row per (instance,
- * quad), then a per-Gaussian reduction + chain rule.  Every element of every non-NULL GsrGrads array is
+/* Backward: back-to-front replay per 8x8 pixel quad (one independent list walk per 4x4 block) writing one dense
+ * gradient row per (instance, block) the forward blended, then a per-Gaussian reduction + chain rule.  Every element of every non-NULL GsrGrads array is
  * written (no pre-zeroing needed).  Deterministic: no floating-point atomics. */
 int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int32_t num_rendered,
                      const int32_t* radii, const void* geom, const void* binning,
@@ -149,9 +149,10 @@ int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int32_t num_ren
 
 /* Introspection of the saved buffers, for parity tests.  Writes byte offset and size of a named
  * field inside buffer `which` for a problem of N Gaussians, D instances, W x H pixels.
- * Names: GEOM: "splat" f32[N,20], "clamped" u32[N], "tiles_touched" u32[N], "inst_begin" u32[N],
- *        "depth_key" u32[N];  BINNING: "point_list" u32[D], "inst_row" u32[D],
- *        "ranges" u32[tiles,2], "stream" f32[D,20] (splat records in (tile, depth) order);  IMAGE: "final_T" f32[3,H,W], "n_contrib" u32[2,H,W]. */
+ * Names: GEOM: "splat" f32[N,20], "clamped" u32[N], "tiles_touched" u32[N], "depth_key" u32[N],
+ *        "order" u32[N] (depth rank -> Gaussian id), "offs" u32[N+1] (depth rank -> first emission index);
+ *        BINNING: "point_list" u32[D], "inst_row" u32[D] (emission index of each list entry), "ranges" u32[tiles,2];
+ *        IMAGE: "final_T" f32[3,H,W], "n_contrib" u32[2,H,W]. */
 int32_t gsr_buffer_field(int32_t which, const char* name, int32_t N, int32_t D, int32_t W,
                          int32_t H, size_t* offset, size_t* bytes);
 
