@@ -14,9 +14,12 @@
  *
  * Conventions
  *   - every pointer marked `device` is HIP device memory owned by the CALLER; the library never
- *     frees or retains it and keeps no global mutable state besides the opt-in profiler;
+ *     frees or retains it and keeps no global mutable state besides the opt-in profiler and one
+ *     64-byte pinned host slot per calling thread (the read-back below);
  *   - all work is enqueued on `stream`; gsr_forward performs exactly one stream synchronisation
  *     (to learn the number of tile instances) before it asks for the instance-sized buffers;
+ *     gsr_backward synchronises only for scenes whose worst-case gradient rows exceed
+ *     GSR_EXACT_ROWS_BYTES (environment, default 8 GiB), to size that buffer exactly;
  *   - matrices are row-major 4x4 in the reference's transposed / row-vector convention
  *     (viewmatrix = W2C^T, projmatrix = viewmatrix @ P^T; scene/cameras.py:56-58);
  *   - return value 0 = ok, negative = GSR_E_*; gsr_last_error() gives the thread's last message.
@@ -109,7 +112,7 @@ enum { GSR_BUF_GEOM = 0, GSR_BUF_BINNING = 1, GSR_BUF_IMAGE = 2, GSR_BUF_SCRATCH
 typedef void* (*gsr_alloc_fn)(void* ctx, int32_t which, size_t bytes);
 
 typedef struct GsrForwardOut {
-    float* out_color;      /* device [3,H,W]                                          */
+    float* out_color;      /* device [channels,H,W]                                   */
     float* out_allmap;     /* device [7,H,W]: depth, alpha, normal xyz (view space), median
                               depth, distortion (gaussian_renderer/__init__.py:117-141) */
     int32_t* radii;        /* device [N]                                              */
