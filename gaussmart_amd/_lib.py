@@ -137,6 +137,8 @@ def lib():
         L.gsr_compact_apply.restype = C.c_int32
         L.gsr_compact_apply.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gsr_densify_stats.restype = C.c_int32
+        L.gsr_densify_stats.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gsr_profile_enable.restype = None
         L.gsr_profile_enable.argtypes = [C.c_int32]
         L.gsr_profile_reset.restype = None

@@ -82,3 +82,34 @@ extern "C" int32_t gsr_compact_apply(int32_t count, const void* const* src, void
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }
+
+// Densification statistics of one iteration (train.py:199-203, scene/gaussian_model.py:551-553) in one launch and
+// without the host synchronisation of the reference's boolean-mask indexing:
+//   visible = radii > 0;  max_radii2D[visible] = max(max_radii2D, radii);
+//   xyz_gradient_accum[visible] += ||means2D.grad||;  denom[visible] += 1
+__global__ void __launch_bounds__(256) densify_stats_kernel(int n, const int32_t* __restrict__ radii,
+                                                            const float* __restrict__ grad2d, float* __restrict__ max_radii,
+                                                            float* __restrict__ accum, float* __restrict__ denom) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    max_radii[i] = fmaxf(max_radii[i], (float)r);
+    const float gx = grad2d[3 * i], gy = grad2d[3 * i + 1], gz = grad2d[3 * i + 2];
+    accum[i] += sqrtf(gx * gx + gy * gy + gz * gz);
+    denom[i] += 1.0f;
+}
+
+extern "C" int32_t gsr_densify_stats(int32_t n, const int32_t* radii, const float* grad2d, float* max_radii2D,
+                                     float* xyz_gradient_accum, float* denom, gsr_stream_t stream_) {
+    if (n < 0 || (n > 0 && (!radii || !grad2d || !max_radii2D || !xyz_gradient_accum || !denom))) {
+        gsr_set_error("bad densify_stats arguments");
+        return GSR_E_INVALID;
+    }
+    if (n == 0) return GSR_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(densify_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, radii, grad2d, max_radii2D,
+                       xyz_gradient_accum, denom);
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}

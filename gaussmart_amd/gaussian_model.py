@@ -355,3 +355,22 @@ class GaussianModel:
         # norm over all three components: the rasterizer guarantees .z == 0  [:551-553]
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter], dim=-1, keepdim=True)
         self.denom[update_filter] += 1
+
+    def update_densification_stats(self, viewspace_point_tensor, radii):
+        """max_radii2D + add_densification_stats of one iteration (train.py:199-203).  On a HIP device: ONE kernel and
+        no host synchronisation (boolean-mask indexing synchronises on nonzero()); elsewhere the reference's ops."""
+        grad = viewspace_point_tensor.grad
+        fused = (radii.is_cuda and grad is not None and grad.is_contiguous() and radii.dtype == torch.int32
+                 and all(t.is_contiguous() and t.dtype == torch.float32 for t in (self.max_radii2D, self.xyz_gradient_accum, self.denom)))
+        if not fused:
+            vis = radii > 0
+            self.max_radii2D[vis] = torch.max(self.max_radii2D[vis], radii[vis].to(self.max_radii2D.dtype))
+            self.add_densification_stats(viewspace_point_tensor, vis)
+            return
+        import ctypes as C
+        from . import _lib
+        with torch.cuda.device(radii.device):
+            _lib.check(_lib.lib().gsr_densify_stats(
+                radii.shape[0], C.c_void_p(radii.data_ptr()), C.c_void_p(grad.data_ptr()), C.c_void_p(self.max_radii2D.data_ptr()),
+                C.c_void_p(self.xyz_gradient_accum.data_ptr()), C.c_void_p(self.denom.data_ptr()),
+                C.c_void_p(torch.cuda.current_stream(radii.device).cuda_stream)))

@@ -91,9 +91,7 @@ def densification_step(gaussians, render_pkg, opt, iteration, cameras_extent, wh
     if view_parallel is not None:
         view_parallel.finish()       # a pipelined step may still be updating the SH tensors on its side stream
     with torch.no_grad():
-        vis, radii = render_pkg["visibility_filter"], render_pkg["radii"]
-        gaussians.max_radii2D[vis] = torch.max(gaussians.max_radii2D[vis], radii[vis].to(gaussians.max_radii2D.dtype))
-        gaussians.add_densification_stats(render_pkg["viewspace_points"], vis)
+        gaussians.update_densification_stats(render_pkg["viewspace_points"], render_pkg["radii"])
         if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
             gen = None
             if view_parallel is not None:

@@ -230,6 +230,12 @@ int32_t gsr_compact_plan(const uint8_t* keep, int64_t n_rows, void* ws, size_t w
 int32_t gsr_compact_apply(int32_t count, const void* const* src, void* const* dst, const int32_t* row_bytes,
                           int64_t n_rows, const uint8_t* keep, const uint32_t* offsets, gsr_stream_t stream);
 
+/* Densification statistics of one iteration (train.py:199-203; scene/gaussian_model.py:551-553) in one launch, no host
+ * synchronisation: for radii[i] > 0: max_radii2D[i] = max(max_radii2D[i], radii[i]); xyz_gradient_accum[i] +=
+ * ||grad2d[i,:]||; denom[i] += 1.  grad2d = means2D.grad [N,3]; the three state arrays are device f32 [N]. */
+int32_t gsr_densify_stats(int32_t n, const int32_t* radii, const float* grad2d, float* max_radii2D,
+                          float* xyz_gradient_accum, float* denom, gsr_stream_t stream);
+
 /* Opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline figures).
  * `mask`: bit k enables kernel k in the order of the names below (-1 = all, 0 = off); timing only
  * the few big kernels keeps the event overhead out of the measured step.

@@ -46,3 +46,25 @@ def test_prune_points_on_device_equals_host(gpu_device):
         torch.testing.assert_close(sa["exp_avg"].cpu(), sb["exp_avg"], rtol=1e-5, atol=1e-9)
         torch.testing.assert_close(sa["exp_avg_sq"].cpu(), sb["exp_avg_sq"], rtol=1e-5, atol=1e-12)
     assert torch.equal(a.max_radii2D.cpu(), b.max_radii2D) and torch.equal(a._segments.cpu(), b._segments)
+
+
+def test_fused_densification_stats_equal_reference_ops(gpu_device):
+    from gaussmart_amd.gaussian_model import GaussianModel
+    from gaussmart_amd.synthetic import make_scene
+    params, _ = make_scene(5000, 64, 64, seed=3)
+    g = torch.Generator().manual_seed(4)
+    radii = torch.randint(-1, 30, (5000,), generator=g, dtype=torch.int32)
+    grad = torch.randn(5000, 3, generator=g)
+    outs = []
+    for dev in (gpu_device, torch.device("cpu")):
+        m = GaussianModel(3, device=dev)
+        m.create_from_params(params)
+        m.xyz_gradient_accum = torch.rand(5000, 1, generator=torch.Generator().manual_seed(5)).to(dev)
+        m.denom = torch.ones(5000, 1, device=dev)
+        m.max_radii2D = torch.full((5000,), 7.0, device=dev)
+        pts = torch.zeros(5000, 3, device=dev, requires_grad=True)
+        pts.grad = grad.to(dev)
+        m.update_densification_stats(pts, radii.to(dev))
+        outs.append((m.max_radii2D.cpu(), m.xyz_gradient_accum.cpu(), m.denom.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-6, atol=1e-7)
