@@ -66,7 +66,7 @@ class Camera(torch.nn.Module):
         self.R, self.T, self.FoVx, self.FoVy = R, T, FoVx, FoVy
         self.data_device = torch.device(data_device)
         if image is not None:
-            self.original_image = image.clamp(0.0, 1.0)
+            self.original_image = image.clamp(0.0, 1.0).to(self.data_device)    # scene/cameras.py:40: resident on the device
             self.image_width, self.image_height = image.shape[2], image.shape[1]
         else:
             self.original_image = None
