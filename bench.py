@@ -128,6 +128,12 @@ def main():
     ap.add_argument("--cpu-tiles", type=int, default=1600)   # ~20 % of the frame: 15-20 s of host work
     args = ap.parse_args()
 
+    # Rank 0 must print exactly ONE line on stdout, but RCCL writes a version banner to fd 1 when the first
+    # communicator is created: park the real stdout and send everything else (library chatter included) to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -160,6 +166,8 @@ def main():
     pipe, opt = PipelineParams(), OptimizationParams()
     if os.environ.get("GSR_BENCH_PLAIN_ACTIVATIONS"):      # A/B aid: torch activations + reference-signature operator
         pipe.fused_activations = False
+    if os.environ.get("GSR_BENCH_UNFACTORED"):             # A/B aid: explicit SH gradient tensors (58 floats per Gaussian)
+        pipe.factored_sh_grad = False
 
     target = GaussianModel(3, device=dev)
     target.create_from_params(perturb(params))
@@ -268,7 +276,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             log(f"GPU part done ({out['value']:.2f} it/s, D={D}); timing the CPU oracle on {host_cores()} cores")
             out["cpu_baseline"] = cpu_baseline(params, cam, args.cpu_tiles, N, dbg, W, H)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgsr_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 GSR_BUF_GEOM, GSR_BUF_BINNING, GSR_BUF_IMAGE, GSR_BUF_SCRATCH, GSR_BUF_SCRATCH2 = range(5)
 GSR_BUF_SYNC_SH = 100     # not a buffer: "the SH colour pass is about to be enqueued" (GSR_FLAG_DEFER_COLOR)
@@ -25,6 +25,7 @@ GSR_FLAGS_UPSTREAM = 3
 GSR_FLAG_DEBUG_NO_CULL = 4
 GSR_FLAG_RAW_PARAMS = 8
 GSR_FLAG_DEFER_COLOR = 16
+GSR_FLAG_FACTORED_SH_GRAD = 32   # backward writes the masked colour gradient [N,3] instead of the SH gradient arrays
 
 KERNEL_NAMES = ("preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",
                 "finalize_bins", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "loss_fwd", "loss_bwd",
@@ -130,6 +131,12 @@ def lib():
         L.gsr_adam_step.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_float),
                                     C.POINTER(C.c_float), C.c_double, C.c_double, C.c_double, C.c_void_p]
+        L.gsr_adam_sh_factored.restype = C.c_int32
+        L.gsr_adam_sh_factored.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                           C.c_int64, C.c_void_p, C.c_int32, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                           C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.gsr_compact_workspace_bytes.restype = C.c_size_t
         L.gsr_compact_workspace_bytes.argtypes = [C.c_int64]
         L.gsr_compact_plan.restype = C.c_int32

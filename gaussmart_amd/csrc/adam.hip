@@ -7,6 +7,7 @@
 // momentum, exactly as with the reference's optimiser.
 // Pure HBM streaming: 16 B read + 12 B written per parameter (1.62 GB at 1M Gaussians).
 #include "gsr_common.h"
+#include "sh_basis.h"
 
 #define AD_BLOCK 256
 typedef float ad_f4 __attribute__((ext_vector_type(4)));   // the non-temporal builtins want a native vector type
@@ -96,6 +97,154 @@ extern "C" int32_t gsr_adam_step(int32_t count, float* const* params, const floa
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;      // grid-stride beyond 16 blocks per CU
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(AD_BLOCK), 0, s, b);
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Adam step of the SH tensors from FACTORED gradients (include/gsr.h: gsr_adam_sh_factored).
+// One wave64 owns 64 consecutive Gaussians:
+//   1. lane = Gaussian: grad[k][c] = scale * sum_views basis_k(dir_view) * g_view[c] in 48 registers, written to a
+//      wave-private LDS tile (rows of 49 floats: lane-per-row writes and element-order reads are conflict free);
+//   2. the wave streams its contiguous 64 x (M-1) x 3 block of features_rest (parameter, two moments) with 16-byte
+//      accesses, three vectors of each array in flight per lane, taking the gradient of every element from the tile;
+//   3. the same for the 64 x 3 block of features_dc.
+// No workgroup barrier (the tile is wave-private).  HBM traffic: 28 B per parameter minus the 4 B gradient read,
+// plus 12 B x (1 + n_views) per Gaussian.
+#define AS_BLOCK 256
+#define AS_ROW 49
+#define AS_MAX_VIEWS 16
+
+struct AdamShParams {
+    int first, count, M, deg, n_views, campos_stride;
+    long long view_stride;
+    float grad_scale;
+    const float* xyz; const float* cg; const float* campos;
+    float* p_dc; float* m_dc; float* v_dc; float* p_rest; float* m_rest; float* v_rest;
+    float ss_dc, ib_dc, ss_rest, ib_rest;
+    float beta2, omb1, omb2, eps;
+};
+
+// Adam over the wave's n_f contiguous floats of one tensor starting at float offset `off`; element e belongs to tile
+// row e / row_f, column col0 + e % row_f.
+__device__ __forceinline__ void adam_sh_segment(const float* wl, int col0, int row_f, float* __restrict__ p,
+                                                float* __restrict__ m, float* __restrict__ v, long long off, int n_f,
+                                                float ss, float ib, const AdamShParams& a, int lane) {
+    p += off; m += off; v += off;
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const int n4 = vec ? n_f >> 2 : 0;
+    constexpr int U = 3;
+    for (int i0 = lane; i0 < n4; i0 += 64 * U) {
+        float4 pp[U], mm[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < n4) { pp[u] = reinterpret_cast<float4*>(p)[i]; mm[u] = nt_load4(m, i); vv[u] = nt_load4(v, i); }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < n4) {
+                const int e = i << 2;
+                int r = e / row_f, c = e - r * row_f;
+                float* P = reinterpret_cast<float*>(&pp[u]);
+                float* Mo = reinterpret_cast<float*>(&mm[u]);
+                float* V = reinterpret_cast<float*>(&vv[u]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float g = wl[r * AS_ROW + col0 + c];
+                    adam_one(P[k], g, Mo[k], V[k], a.omb1, a.beta2, a.omb2, a.eps, ss, ib);
+                    if (++c == row_f) { c = 0; ++r; }
+                }
+                reinterpret_cast<float4*>(p)[i] = pp[u];
+                nt_store4(m, i, mm[u]);
+                nt_store4(v, i, vv[u]);
+            }
+        }
+    }
+    for (int e = (n4 << 2) + lane; e < n_f; e += 64) {
+        const int r = e / row_f, c = e - r * row_f;
+        float pp = p[e], mm = m[e], vv = v[e];
+        adam_one(pp, wl[r * AS_ROW + col0 + c], mm, vv, a.omb1, a.beta2, a.omb2, a.eps, ss, ib);
+        p[e] = pp; m[e] = mm; v[e] = vv;
+    }
+}
+
+__global__ void __launch_bounds__(AS_BLOCK) adam_sh_factored_kernel(AdamShParams a) {
+    __shared__ float tile[AS_BLOCK / 64][64 * AS_ROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rel = (blockIdx.x * (AS_BLOCK / 64) + wave) * 64;      // first Gaussian of this wave, relative to a.first
+    const int n_here = min(64, a.count - rel);
+    if (n_here <= 0) return;                                          // wave-uniform; no workgroup barrier below
+    const int wave_first = a.first + rel;
+    float* wl = tile[wave];
+
+    if (lane < n_here) {
+        const int idx = wave_first + lane;
+        const float px = a.xyz[3 * (size_t)idx + 0], py = a.xyz[3 * (size_t)idx + 1], pz = a.xyz[3 * (size_t)idx + 2];
+        float acc[48];
+#pragma unroll
+        for (int j = 0; j < 48; ++j) acc[j] = 0.f;
+        for (int r = 0; r < a.n_views; ++r) {
+            const float* gp = a.cg + (size_t)r * a.view_stride + 3 * (size_t)idx;
+            const float g0 = gp[0], g1 = gp[1], g2 = gp[2];
+            if (g0 != 0.f || g1 != 0.f || g2 != 0.f) {
+                const float* cp = a.campos + r * a.campos_stride;
+                const float ox = px - cp[0], oy = py - cp[1], oz = pz - cp[2];
+                const float il = 1.0f / sqrtf(ox * ox + oy * oy + oz * oz);
+                float basis[16];
+                sh_basis16(a.deg, ox * il, oy * il, oz * il, basis);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    acc[3 * k + 0] = fmaf(basis[k], g0, acc[3 * k + 0]);
+                    acc[3 * k + 1] = fmaf(basis[k], g1, acc[3 * k + 1]);
+                    acc[3 * k + 2] = fmaf(basis[k], g2, acc[3 * k + 2]);
+                }
+            }
+        }
+        const float sc = a.grad_scale;
+#pragma unroll
+        for (int j = 0; j < 48; ++j)
+            if (j < 3 * a.M) wl[lane * AS_ROW + j] = acc[j] * sc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const int rest_f = (a.M - 1) * 3;
+    if (rest_f > 0)
+        adam_sh_segment(wl, 3, rest_f, a.p_rest, a.m_rest, a.v_rest, (long long)wave_first * rest_f, n_here * rest_f,
+                        a.ss_rest, a.ib_rest, a, lane);
+    adam_sh_segment(wl, 0, 3, a.p_dc, a.m_dc, a.v_dc, (long long)wave_first * 3, n_here * 3, a.ss_dc, a.ib_dc, a, lane);
+}
+
+extern "C" int32_t gsr_adam_sh_factored(int32_t first, int32_t count, int32_t sh_coeffs, int32_t sh_degree, const float* xyz,
+                                        int32_t n_views, const float* color_grad, int64_t view_stride, const float* campos,
+                                        int32_t campos_stride, float grad_scale,
+                                        float* p_dc, float* m_dc, float* v_dc, float step_size_dc, float inv_bc2_sqrt_dc,
+                                        float* p_rest, float* m_rest, float* v_rest, float step_size_rest,
+                                        float inv_bc2_sqrt_rest, double beta1, double beta2, double eps,
+                                        gsr_stream_t stream_) {
+    if (first < 0 || count < 0 || sh_coeffs < 1 || sh_coeffs > 16 || sh_degree < 0 || sh_degree > 3 ||
+        n_views < 1 || n_views > AS_MAX_VIEWS || campos_stride < 3 || view_stride < 0) {
+        gsr_set_error("adam_sh_factored: bad sizes (coeffs 1..16, degree 0..3, views 1..%d)", AS_MAX_VIEWS);
+        return GSR_E_INVALID;
+    }
+    if (count == 0) return GSR_OK;
+    if (!xyz || !color_grad || !campos || !p_dc || !m_dc || !v_dc || (sh_coeffs > 1 && (!p_rest || !m_rest || !v_rest))) {
+        gsr_set_error("adam_sh_factored: null argument");
+        return GSR_E_INVALID;
+    }
+    AdamShParams a;
+    a.first = first; a.count = count; a.M = sh_coeffs; a.deg = sh_degree; a.n_views = n_views;
+    a.campos_stride = campos_stride; a.view_stride = view_stride; a.grad_scale = grad_scale;
+    a.xyz = xyz; a.cg = color_grad; a.campos = campos;
+    a.p_dc = p_dc; a.m_dc = m_dc; a.v_dc = v_dc; a.p_rest = p_rest; a.m_rest = m_rest; a.v_rest = v_rest;
+    a.ss_dc = step_size_dc; a.ib_dc = inv_bc2_sqrt_dc; a.ss_rest = step_size_rest; a.ib_rest = inv_bc2_sqrt_rest;
+    a.beta2 = (float)beta2; a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps;
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    GsrProfileScope prof(GSR_K_ADAM, s);
+    const unsigned blocks = (unsigned)((count + AS_BLOCK - 1) / AS_BLOCK);
+    hipLaunchKernelGGL(adam_sh_factored_kernel, dim3(blocks), dim3(AS_BLOCK), 0, s, a);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

@@ -292,9 +292,12 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
                                 GsrGrads* grads, gsr_alloc_fn alloc, void* ctx, gsr_stream_t stream_) {
     int rc = validate(view, g);
     if (rc != GSR_OK) return rc;
+    // factored SH gradient: dL_dcolors [N,3] receives the masked colour gradient, the SH arrays are not written
+    const bool factored = (view->flags & (uint32_t)GSR_FLAG_FACTORED_SH_GRAD) != 0 && g->shs != nullptr;
     if (!grads || !alloc || !geom || !binning || !image || !dL_dcolor || !dL_dallmap || num_rendered < 0 ||
         (g->count > 0 && (!radii || !grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacity)) ||
-        (g->shs && !grads->dL_dshs) || (g->shs_rest && !grads->dL_dshs_rest) || (g->colors_precomp && !grads->dL_dcolors) ||
+        (g->shs && !factored && !grads->dL_dshs) || (g->shs_rest && !factored && !grads->dL_dshs_rest) ||
+        (factored && !grads->dL_dcolors) || (g->colors_precomp && !grads->dL_dcolors) ||
         (g->scales && (!grads->dL_dscales || !grads->dL_drotations)) ||
         (g->transmat_precomp && !grads->dL_dtransmat)) {
         gsr_set_error("backward inputs / gradient outputs missing");
@@ -364,7 +367,8 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     GsrGrads o = *grads;
     if (!g->shs) o.dL_dshs = nullptr;
     if (!g->shs_rest) o.dL_dshs_rest = nullptr;
-    if (!g->colors_precomp) o.dL_dcolors = nullptr;
+    if (!g->colors_precomp && !factored) o.dL_dcolors = nullptr;
+    if (factored) { o.dL_dshs = nullptr; o.dL_dshs_rest = nullptr; }
     if (!g->scales) { o.dL_dscales = nullptr; o.dL_drotations = nullptr; }
     if (!g->transmat_precomp) o.dL_dtransmat = nullptr;
     rc = gsr_launch_reduce_rows(N, at<uint32_t>(geom, GL.order), at<uint32_t>(geom, GL.offs), slot_off, grad_rows,

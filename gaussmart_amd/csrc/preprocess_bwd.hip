@@ -10,6 +10,8 @@
 // Restates the [U] preprocess backward; differentiates preprocess_fwd.hip exactly (same anchors).
 // HBM-bound: reads 80 B x instances + 232 B, writes 232 B (192 of them dSH) per Gaussian; the SH
 // block is staged through LDS both ways so global traffic is coalesced 16-byte accesses.
+// GSR_FLAG_FACTORED_SH_GRAD: the 192 B of dSH are replaced by the 12 B masked colour gradient (the optimiser
+// rebuilds basis x g itself, adam.hip), followed by the camera position in the 4 floats after the [N,3] block.
 #include "gsr_common.h"
 #include "sh_stage.h"
 #include "wave_reduce.h"
@@ -22,6 +24,7 @@ struct PreBwdParams {
     float mod;
     const float* view; const float* proj; const float* campos;
     bool raw;
+    bool factored;      // GSR_FLAG_FACTORED_SH_GRAD: masked colour gradient out, no SH gradient arrays
     const float* means; const float* shs; const float* shs_rest; const float* opac; const float* scales; const float* rots;
     const float* tprecomp;
     const int32_t* radii; const float* splat; const uint32_t* clamped;
@@ -282,7 +285,16 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
             dmean[1] += (ddy - y * dotp) * il;
             dmean[2] += (ddz - z * dotp) * il;
         }
-        if (STAGE_SH) {
+        if (p.factored) {
+            // the optimiser rebuilds basis_k x g itself (gsr_adam_sh_factored): 12 bytes out instead of 192
+            if (valid) {
+                p.out.dL_dcolors[3 * idx + 0] = g[0]; p.out.dL_dcolors[3 * idx + 1] = g[1]; p.out.dL_dcolors[3 * idx + 2] = g[2];
+            }
+            if (idx == 0) {      // the record of a view is self-contained: [N,3] colour gradient + camera position
+                float* tail = p.out.dL_dcolors + 3 * (size_t)p.N;
+                tail[0] = p.campos[0]; tail[1] = p.campos[1]; tail[2] = p.campos[2]; tail[3] = 0.f;
+            }
+        } else if (STAGE_SH) {
             // overwrite the staged coefficients with their gradients, then stream the tile out
             __builtin_amdgcn_wave_barrier();
             if (valid) {
@@ -319,7 +331,7 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
         dopa *= o * (1.0f - o);                                 // d sigmoid
     }
     p.out.dL_dopacity[idx] = dopa;
-    if (p.out.dL_dcolors) {
+    if (p.out.dL_dcolors && !p.factored) {
         p.out.dL_dcolors[3 * idx + 0] = drgb[0]; p.out.dL_dcolors[3 * idx + 1] = drgb[1]; p.out.dL_dcolors[3 * idx + 2] = drgb[2];
     }
     if (p.out.dL_dscales) { p.out.dL_dscales[2 * idx + 0] = dscale0; p.out.dL_dscales[2 * idx + 1] = dscale1; }
@@ -341,13 +353,16 @@ int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int
     p.N = g.count; p.W = v.width; p.H = v.height; p.deg = v.sh_degree; p.M = v.sh_coeffs;
     p.mod = v.scale_modifier; p.view = v.viewmatrix; p.proj = v.projmatrix; p.campos = v.campos;
     p.raw = (v.flags & (uint32_t)GSR_FLAG_RAW_PARAMS) != 0;
+    p.factored = (v.flags & (uint32_t)GSR_FLAG_FACTORED_SH_GRAD) != 0 && g.shs != nullptr;
+    if (p.factored && !out.dL_dcolors) { gsr_set_error("GSR_FLAG_FACTORED_SH_GRAD needs dL_dcolors"); return GSR_E_INVALID; }
     p.means = g.means3D; p.shs = g.shs; p.shs_rest = g.shs_rest; p.opac = g.opacities; p.scales = g.scales; p.rots = g.rotations;
     p.tprecomp = g.transmat_precomp; p.radii = radii; p.splat = splat; p.clamped = clamped;
     p.row_sums = row_sums; p.out = out;
     const int blocks = (g.count + PB_BLOCK - 1) / PB_BLOCK;
     GsrProfileScope prof(GSR_K_PREPROCESS_BWD, s);
-    const bool stage = sh_can_stage(g.shs, g.shs_rest, v.sh_coeffs) && sh_can_stage(out.dL_dshs, out.dL_dshs_rest, v.sh_coeffs);
-    if (g.shs_rest && (!stage || !out.dL_dshs_rest)) { gsr_set_error("split SH storage needs 16-byte aligned pointers, <= 16 coefficients and dL_dshs_rest"); return GSR_E_UNSUPPORTED; }
+    const bool stage = sh_can_stage(g.shs, g.shs_rest, v.sh_coeffs) &&
+                       (p.factored || sh_can_stage(out.dL_dshs, out.dL_dshs_rest, v.sh_coeffs));
+    if (g.shs_rest && (!stage || (!p.factored && !out.dL_dshs_rest))) { gsr_set_error("split SH storage needs 16-byte aligned pointers, <= 16 coefficients and dL_dshs_rest"); return GSR_E_UNSUPPORTED; }
     if (stage) {
         const size_t lds_bytes = (size_t)(PB_BLOCK / 64) * 64 * SH_ROW_FLOATS * sizeof(float);
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(PB_BLOCK), lds_bytes, s, p);

@@ -15,6 +15,30 @@ class FusedAdam(torch.optim.Adam):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
+        self.pending_sh = None      # (features_dc, features_rest, rasterizer.ColorGradRecord) of the last factored backward
+
+    # ---- factored SH gradient: the two feature parameters have NO .grad after such a backward; their gradient is the
+    # record parked here, which the next full step() turns into an update (so `optimizer.step()` keeps meaning "apply
+    # the gradients of the last backward" for every caller) and zero_grad() drops.
+    def park_sh_gradient(self, f_dc, f_rest, rec):
+        self.pending_sh = None if rec is None else (f_dc, f_rest, rec)
+
+    def take_pending_sh(self):
+        """The parked record if it still matches the parameters, else None; clears the slot.  After a densification
+        the feature tensors were replaced (scene/gaussian_model.py:398-470): like every replaced parameter, whose
+        .grad is None, they then sit this step out."""
+        pend, self.pending_sh = self.pending_sh, None
+        if pend is None:
+            return None
+        f_dc, f_rest, rec = pend
+        live = {id(q) for g in self.param_groups for q in g["params"]}
+        if id(f_dc) not in live or id(f_rest) not in live or rec.n != f_dc.shape[0]:
+            return None
+        return pend
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.pending_sh = None
+        return super().zero_grad(set_to_none=set_to_none)
 
     @torch.no_grad()
     def step(self, closure=None, only=None, stream=None):
@@ -27,6 +51,12 @@ class FusedAdam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
+        if only is None:
+            pend = self.take_pending_sh()
+            if pend is not None:        # first: it reads the positions the backward saw, which the launch below updates
+                f_dc, f_rest, rec = pend
+                self.step_sh_factored(f_dc, f_rest, rec.xyz, rec.gathered if rec.gathered is not None else rec.record,
+                                      rec.n_views, rec.record.numel(), rec.sh_degree, rec.grad_scale, stream=stream)
         batches = {}
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
@@ -87,3 +117,55 @@ class FusedAdam(torch.optim.Adam):
                 1, ptr(p), ptr(p.grad), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), (C.c_int64 * 1)(int(stop - start)),
                 (C.c_float * 1)(group["lr"] / (1.0 - beta1 ** t)), (C.c_float * 1)(1.0 / math.sqrt(1.0 - beta2 ** t)),
                 beta1, beta2, group["eps"], C.c_void_p(stream_h)))
+
+    def _state_of(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def step_sh_factored(self, f_dc, f_rest, xyz, records, n_views, view_stride, sh_degree, grad_scale=1.0,
+                         first=0, count=None, stream=None, count_step=True):
+        """Adam update of the two SH parameters from FACTORED gradients (include/gsr.h: gsr_adam_sh_factored):
+        `records` holds n_views blocks of `view_stride` floats, each the [N,3] clamp-masked colour gradient of one view
+        followed by that view's camera position (rasterizer.ColorGradRecord.record, or the all-gather of it over the
+        ranks of a view-parallel step).  `xyz` must be the positions the backward saw: call this BEFORE updating xyz,
+        or pass a snapshot.  [first, first + count) restricts the update to a range of Gaussians; `count_step=False`
+        for every range after the first one of an iteration."""
+        L = _lib.lib()
+        N = f_dc.shape[0]
+        count = N - first if count is None else count
+        if count <= 0:
+            return
+        for t in (f_dc, f_rest, xyz, records):
+            if t.device.type != "cuda" or t.dtype != torch.float32 or not t.is_contiguous():
+                raise _lib.GsrError("step_sh_factored needs contiguous float32 tensors on a HIP device")
+        if f_rest.shape[0] != N or xyz.shape[0] != N or view_stride < 3 * N + 3 or records.numel() < n_views * view_stride:
+            raise _lib.GsrError("step_sh_factored: shapes do not match")
+        ptrs, sizes = [], []
+        for p in (f_dc, f_rest):
+            group = next(g for g in self.param_groups if any(q is p for q in g["params"]))
+            st = self._state_of(p)
+            if count_step:
+                st["step"] += 1
+            t = float(st["step"])
+            beta1, beta2 = group["betas"]
+            ptrs.append((p, st["exp_avg"], st["exp_avg_sq"], group["lr"] / (1.0 - beta1 ** t), 1.0 / math.sqrt(1.0 - beta2 ** t)))
+            sizes.append((beta1, beta2, group["eps"]))
+        if sizes[0] != sizes[1]:
+            raise _lib.GsrError("step_sh_factored: f_dc and f_rest must share betas and eps")
+        (beta1, beta2, eps) = sizes[0]
+        M = 1 + f_rest.shape[1]
+        with torch.cuda.device(f_dc.device):
+            stream_h = (stream if stream is not None else torch.cuda.current_stream(f_dc.device)).cuda_stream
+            a, b = ptrs
+            _lib.check(L.gsr_adam_sh_factored(
+                int(first), int(count), M, int(sh_degree), C.c_void_p(xyz.data_ptr()), int(n_views),
+                C.c_void_p(records.data_ptr()), int(view_stride), C.c_void_p(records.data_ptr() + 12 * N), int(view_stride),
+                float(grad_scale),
+                C.c_void_p(a[0].data_ptr()), C.c_void_p(a[1].data_ptr()), C.c_void_p(a[2].data_ptr()), a[3], a[4],
+                C.c_void_p(b[0].data_ptr()), C.c_void_p(b[1].data_ptr()), C.c_void_p(b[2].data_ptr()), b[3], b[4],
+                beta1, beta2, eps, C.c_void_p(stream_h)))

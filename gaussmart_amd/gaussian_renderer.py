@@ -7,6 +7,8 @@
 
 The extra keyword `surface_maps=False` skips the five derived maps: the trainer's fast path feeds
 `allmap` to the fused regularizer kernels instead (gaussmart_amd/fused_regularizer.py).
+`factored_sh_grad=True` (only honoured on the raw-parameter path; set by trainer.training_step, which owns the
+optimiser step) makes the backward leave the colour gradient [N,3] instead of the two SH gradient tensors.
 
 Device follows the model's tensors (the reference hard-codes "cuda").
 """
@@ -106,7 +108,7 @@ def _use_raw_path(pc, pipe, override_color, xyz):
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, *,
-           surface_maps=True):
+           surface_maps=True, factored_sh_grad=False):
     xyz = pc.get_xyz
     device = xyz.device
     # the reference adds 0 and calls retain_grad() (gaussian_renderer/__init__.py:27-31); a leaf that requires
@@ -155,7 +157,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if raw:
         # same kernels, activations + dc|rest concatenation fused inside (rasterizer.py: _RasterizeGaussiansRaw)
         rendered_image, radii, allmap = rasterize_gaussians_raw(
-            xyz, means2D, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation, raster_settings)
+            xyz, means2D, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation, raster_settings,
+            factored_sh_grad=factored_sh_grad and pc._features_rest.shape[1] > 0)
     else:
         rendered_image, radii, allmap = rasterizer(
             means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,

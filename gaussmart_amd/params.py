@@ -20,6 +20,9 @@ class PipelineParams:
     # not in the reference: feed the rasterizer the raw parameters and fuse exp / sigmoid / normalize
     # and the dc|rest concatenation into its kernels (same results, ~0.4 ms less per 1M-Gaussian step)
     fused_activations: bool = True
+    # not in the reference: the backward returns dL/drgb [N,3] and the Adam kernel of the SH tensors rebuilds
+    # basis(dir) x dL/drgb itself (48 -> 3 gradient floats per Gaussian written, read and exchanged between GPUs)
+    factored_sh_grad: bool = True
 
 
 @dataclass

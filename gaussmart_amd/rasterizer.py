@@ -213,6 +213,30 @@ def wait_pending_params(device):
         torch.cuda.current_stream(device).wait_event(ev)
 
 
+class ColorGradRecord:
+    """Factored SH gradient of ONE backward (GSR_FLAG_FACTORED_SH_GRAD): instead of dL/d(features_dc) and
+    dL/d(features_rest) -- 48 floats per Gaussian -- the backward leaves the clamp-masked colour gradient [N,3]
+    followed by the camera position in `record` (f32[3N + 4]); gsr_adam_sh_factored rebuilds basis_k(dir) x g inside
+    the optimiser step.  `flat` = [xyz | opacity | scaling | rotation | record] is one allocation, `head` its first
+    four segments (what a view-parallel step all-reduces), `xyz` the positions the backward saw."""
+    __slots__ = ("flat", "head", "record", "n", "sh_coeffs", "sh_degree", "xyz", "exchanged", "gathered", "n_views",
+                 "grad_scale")
+
+    def __init__(self, flat, head, record, n, sh_coeffs, sh_degree, xyz):
+        self.flat, self.head, self.record, self.n = flat, head, record, int(n)
+        self.sh_coeffs, self.sh_degree, self.xyz = int(sh_coeffs), int(sh_degree), xyz
+        # filled by ViewParallel.exchange_factored: records of all ranks, their number, 1 / world when averaging
+        self.exchanged, self.gathered, self.n_views, self.grad_scale = False, None, 1, 1.0
+
+
+_COLOR_GRAD = {}
+
+
+def take_color_grad(device):
+    """The ColorGradRecord the last factored backward on `device` left (None if there was none); clears the slot."""
+    return _COLOR_GRAD.pop(torch.device(device), None)
+
+
 def release_workspace():
     """Drop every cached library buffer (e.g. before handing the GPU to something else)."""
     _POOL.clear()
@@ -427,15 +451,27 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             # ONE buffer for the six parameter gradients, [xyz | f_dc | opacity | scaling | rotation | f_rest]: the
             # data-parallel step all-reduces it as a whole (or as "geometry + dc" / "rest" halves) without copies
             d_2d = torch.empty((N, 3), dtype=torch.float32, device=device)
-            srcs = (xyz, f_dc, opacity_raw, scaling_raw, rotation_raw, f_rest)
+            factored = bool(ctx.flags & _lib.GSR_FLAG_FACTORED_SH_GRAD)
+            srcs = (xyz, opacity_raw, scaling_raw, rotation_raw) if factored else \
+                (xyz, f_dc, opacity_raw, scaling_raw, rotation_raw, f_rest)
             offs, total = [], 0
             for t in srcs:                       # every segment starts 16-byte aligned (K8 stores float4)
                 offs.append(total)
                 total += _round_up(t.numel(), 4)
-            flat = torch.empty(total, dtype=torch.float32, device=device)
-            d_xyz, d_dc, d_op, d_sc, d_rot, d_rest = [flat[o:o + t.numel()].view_as(t) for o, t in zip(offs, srcs)]
-            grads = _lib.GsrGrads(_ptr(d_xyz), _ptr(d_2d), _ptr(d_op), _ptr(d_dc), None, _ptr(d_sc), _ptr(d_rot), None,
-                                  _ptr(d_rest) if rest is not None else None)
+            if factored:
+                # [xyz | opacity | scaling | rotation | colour gradient [N,3] + camera position]: 13 floats per Gaussian
+                n_head = total
+                flat = torch.empty(n_head + 3 * N + 4, dtype=torch.float32, device=device)
+                d_xyz, d_op, d_sc, d_rot = [flat[o:o + t.numel()].view_as(t) for o, t in zip(offs, srcs)]
+                d_dc = d_rest = None
+                record = flat[n_head:]
+                grads = _lib.GsrGrads(_ptr(d_xyz), _ptr(d_2d), _ptr(d_op), None, _ptr(record), _ptr(d_sc), _ptr(d_rot),
+                                      None, None)
+            else:
+                flat = torch.empty(total, dtype=torch.float32, device=device)
+                d_xyz, d_dc, d_op, d_sc, d_rot, d_rest = [flat[o:o + t.numel()].view_as(t) for o, t in zip(offs, srcs)]
+                grads = _lib.GsrGrads(_ptr(d_xyz), _ptr(d_2d), _ptr(d_op), _ptr(d_dc), None, _ptr(d_sc), _ptr(d_rot), None,
+                                      _ptr(d_rest) if rest is not None else None)
             alloc = _Allocator(device)
             stream = torch.cuda.current_stream(device).cuda_stream
             rc = L.gsr_backward(C.byref(view), C.byref(g), ctx.num_rendered, _ptr(radii), _ptr(geom), _ptr(binning),
@@ -447,14 +483,21 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             _lib.check(rc)
         del keep
         _finish_lease(ctx)
+        if factored:
+            _COLOR_GRAD[torch.device(device)] = ColorGradRecord(flat, flat[:n_head], record, N, ctx.M, rs.sh_degree, xyz)
         return d_xyz, d_2d, d_dc, d_rest, d_op, d_sc, d_rot, None, None
 
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
-                            raster_settings, flags=None):
-    """(color, radii, allmap) from the model's raw parameter tensors; activations fused in-kernel."""
+                            raster_settings, flags=None, factored_sh_grad=False):
+    """(color, radii, allmap) from the model's raw parameter tensors; activations fused in-kernel.
+    `factored_sh_grad`: the backward leaves NO gradient on features_dc / features_rest; it parks a ColorGradRecord
+    (take_color_grad) for FusedAdam.step_sh_factored instead -- only for callers that own the optimiser step."""
+    flags = DEFAULT_FLAGS if flags is None else flags
+    if factored_sh_grad:
+        flags |= _lib.GSR_FLAG_FACTORED_SH_GRAD
     return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
-                                        rotation_raw, raster_settings, DEFAULT_FLAGS if flags is None else flags)
+                                        rotation_raw, raster_settings, flags)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,

@@ -12,6 +12,8 @@ import time
 import torch
 
 from .gaussian_renderer import render
+from .fused_adam import FusedAdam
+from .rasterizer import take_color_grad
 from .fused_loss import photometric_loss as fused_photometric_loss
 from .fused_objective import training_objective
 from .losses import l1_loss, ssim
@@ -60,24 +62,50 @@ def training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam=None, pi
     return total, {"l1": Ll1.detach(), "loss": loss.detach(), "normal": normal_loss.detach(), "dist": dist_loss.detach()}
 
 
+def _use_factored_sh_grad(gaussians, pipe, render_fn, on_device):
+    """The backward may leave dL/drgb [N,3] instead of the SH gradient tensors only when this module also performs the
+    optimiser step with the kernel that understands it (FusedAdam.step_sh_factored) on the raw-parameter path."""
+    return (on_device and render_fn is render and getattr(pipe, "factored_sh_grad", False)
+            and getattr(pipe, "fused_activations", False) and isinstance(getattr(gaussians, "optimizer", None), FusedAdam))
+
+
+def optimizer_step(gaussians, view_parallel: ViewParallel = None):
+    """Optimiser step of one iteration, including the gradient exchange of a view-parallel step (unless
+    training_step(step_optimizer=False) already did it: then call this without `view_parallel`)."""
+    optimizer = gaussians.optimizer
+    if view_parallel is not None:
+        rec = optimizer.take_pending_sh() if isinstance(optimizer, FusedAdam) else None
+        view_parallel.reduce_and_step(optimizer, rec[2] if rec is not None else None)   # pipelined when RCCL allows it
+    else:
+        optimizer.step()        # FusedAdam applies a parked factored SH gradient itself
+    optimizer.zero_grad(set_to_none=True)
+
+
 def training_step(gaussians, viewpoint_cam, gt_image, opt, pipe, background, iteration,
                   view_parallel: ViewParallel = None, render_fn=render, step_optimizer=True):
-    """forward + loss + backward (+ gradient all-reduce) (+ Adam).  Returns (render_pkg, losses);
-    nothing is synchronised with the host."""
+    """forward + loss + backward (+ gradient exchange) (+ Adam).  Returns (render_pkg, losses);
+    nothing is synchronised with the host.  With `step_optimizer=False` the gradients are exchanged here (view-parallel
+    runs) and the caller finishes the iteration with optimizer_step(gaussians) or gaussians.optimizer.step() -- train()
+    does, after the densification bookkeeping."""
     gaussians.update_learning_rate(iteration)
     on_device = gaussians.get_xyz.is_cuda
-    render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=not on_device)
+    factored = _use_factored_sh_grad(gaussians, pipe, render_fn, on_device)
+    if factored:
+        render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=False, factored_sh_grad=True)
+    else:
+        render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=not on_device)
     total, parts = training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam, pipe)
     total.backward(gradient=_unit_gradient(total))   # cached: saves the ones_like() fill of every step
-    if view_parallel is not None and step_optimizer:
-        view_parallel.reduce_and_step(gaussians.optimizer)      # pipelined when RCCL + fused kernels allow it
-        gaussians.optimizer.zero_grad(set_to_none=True)
-    else:
-        if view_parallel is not None:
+    rec = take_color_grad(gaussians.get_xyz.device) if factored else None
+    if factored:
+        gaussians.optimizer.park_sh_gradient(gaussians._features_dc, gaussians._features_rest, rec)
+    if step_optimizer:
+        optimizer_step(gaussians, view_parallel)
+    elif view_parallel is not None:
+        if rec is not None:
+            view_parallel.exchange_factored(rec)
+        else:
             view_parallel.allreduce_gradients()
-        if step_optimizer:
-            gaussians.optimizer.step()
-            gaussians.optimizer.zero_grad(set_to_none=True)
     parts["total"] = total.detach()
     return render_pkg, parts
 
@@ -127,8 +155,7 @@ def train(gaussians, cameras, opt, pipe, background, *, cameras_extent=1.0, firs
                                          view_parallel=view_parallel, step_optimizer=False)
         densification_step(gaussians, render_pkg, opt, iteration, cameras_extent, white_background, view_parallel)
         if iteration < iterations:
-            gaussians.optimizer.step()
-            gaussians.optimizer.zero_grad(set_to_none=True)
+            optimizer_step(gaussians)      # the exchange of a view-parallel run already happened in training_step
         if log_every and iteration % log_every == 0:
             log_fn(f"[it {iteration}] loss {float(last['loss']):.5f} points {gaussians.get_xyz.shape[0]} "
                    f"{(iteration - first_iter) / (time.time() - t0):.2f} it/s")

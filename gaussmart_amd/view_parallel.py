@@ -23,6 +23,8 @@ class ViewParallel:
         self.pipelined = (os.environ.get("GSR_DP_PIPELINE", "1") != "0") if pipelined is None else bool(pipelined)
         self._side = None           # side stream of the SH update
         self._pending = None        # event: SH update of the previous step finished
+        self._gathered = None       # factored step: all-gathered colour-gradient records (grow-only)
+        self._xyz_snap = None       # factored pipelined step: the positions the backward saw
 
     @property
     def world_size(self):
@@ -97,8 +99,90 @@ class ViewParallel:
             if p.grad is not gr:
                 p.grad = gr
 
-    def reduce_and_step(self, optimizer):
-        """all-reduce + optimiser step of one iteration.
+    # ------------------------------------------------------------------ factored SH gradient (13 floats per Gaussian)
+    # The SH gradient of one view is the outer product basis(view direction) x dL/drgb, so instead of all-reducing
+    # 48 floats per Gaussian the ranks ALL-GATHER their [N,3] colour gradients (+ camera position) and every rank
+    # rebuilds   mean_r basis(dir_r) x g_r   inside its Adam kernel (fused_adam.FusedAdam.step_sh_factored), in rank
+    # order -- identical bits on every replica.  Wire volume per Gaussian and rank: 40 B all-reduced + 12 B gathered
+    # per peer, instead of 232 B all-reduced.  xGMI is point-to-point (one ~77 GB/s link per direction per GPU pair), so
+    # the volume is what bounds a view-parallel step once the step itself takes 2.3 ms.
+    def _gather_records(self, rec, async_op):
+        world = self.world_size
+        stride = rec.record.numel()
+        need = world * stride
+        if self._gathered is None or self._gathered.numel() < need or self._gathered.device != rec.record.device:
+            self._gathered = torch.empty(need + need // 8, dtype=torch.float32, device=rec.record.device)
+        out = self._gathered[:need]
+        if dist.get_backend(self.pg) == "nccl":
+            work = dist.all_gather_into_tensor(out, rec.record, group=self.pg, async_op=async_op)
+        else:
+            work = dist.all_gather([out[i * stride:(i + 1) * stride] for i in range(world)], rec.record, group=self.pg,
+                                   async_op=async_op)
+        return out, work
+
+    def exchange_factored(self, rec):
+        """Blocking exchange of a factored backward (rasterizer.ColorGradRecord): all-reduce of the geometry gradients
+        in place, all-gather of the colour-gradient records; the result is parked on `rec` for
+        trainer.optimizer_step()."""
+        rec.exchanged, rec.gathered, rec.n_views, rec.grad_scale = True, None, 1, 1.0
+        if self.world_size == 1 and not self.force:
+            return
+        self.finish()
+        use_avg = self.average and dist.get_backend(self.pg) == "nccl"
+        dist.all_reduce(rec.head, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, group=self.pg)
+        if self.average and not use_avg:
+            rec.head.mul_(1.0 / self.world_size)
+        rec.gathered, _ = self._gather_records(rec, False)
+        rec.n_views = self.world_size
+        rec.grad_scale = 1.0 / self.world_size if self.average else 1.0
+
+    def _factored_step(self, optimizer, rec):
+        g = self.g
+        f_dc, f_rest = g._features_dc, g._features_rest
+        stride, deg = rec.record.numel(), rec.sh_degree
+        if self.world_size == 1 and not self.force:
+            optimizer.step_sh_factored(f_dc, f_rest, rec.xyz, rec.record, 1, stride, deg)
+            optimizer.step()
+            return
+        self.finish()                                     # the previous step's SH update (normally long done)
+        if not (self.pipelined and rec.head.is_cuda and dist.get_backend(self.pg) == "nccl"):
+            self.exchange_factored(rec)
+            optimizer.step_sh_factored(f_dc, f_rest, rec.xyz, rec.gathered, rec.n_views, stride, deg, rec.grad_scale)
+            optimizer.step()                              # features have no .grad: skipped there
+            return
+        # Pipelined: the main stream waits only for the 40 MB geometry all-reduce, updates xyz / opacity / scaling /
+        # rotation and starts the next forward; the all-gather of the colour gradients and the SH update run on the
+        # side stream against a snapshot of the positions, and the next forward waits for them right before its SH
+        # colour pass (rasterizer.set_pending_param_event).
+        from . import rasterizer
+        dev = rec.head.device
+        world = self.world_size
+        op = dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM
+        w_head = dist.all_reduce(rec.head, op=op, group=self.pg, async_op=True)
+        out, w_rec = self._gather_records(rec, True)
+        if self._xyz_snap is None or self._xyz_snap.shape != rec.xyz.shape or self._xyz_snap.device != dev:
+            self._xyz_snap = torch.empty_like(rec.xyz)
+        self._xyz_snap.copy_(rec.xyz)
+        snapped = torch.cuda.Event()
+        snapped.record(torch.cuda.current_stream(dev))
+        w_head.wait()                                     # current stream waits for the geometry collective only
+        optimizer.step()                                  # features have no .grad: skipped
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(snapped)
+            w_rec.wait()
+            optimizer.step_sh_factored(f_dc, f_rest, self._xyz_snap, out, world, stride, deg,
+                                       1.0 / world if self.average else 1.0, stream=self._side)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        rec.flat.record_stream(self._side)
+        self._pending = ev
+        rasterizer.set_pending_param_event(dev, ev)
+
+    def reduce_and_step(self, optimizer, rec=None):
+        """all-reduce + optimiser step of one iteration.  `rec`: the factored SH gradient of this iteration's backward
+        (trainer.optimizer_step passes it), handled by _factored_step().
 
         Pipelined form (RCCL, HIP tensors, flat gradient buffer, FusedAdam): the buffer is reduced as two
         collectives -- "geometry + dc" (13 floats per Gaussian) and "SH rest" (45) -- and the main stream only
@@ -108,6 +192,11 @@ class ViewParallel:
         waits for them right before its SH colour pass (rasterizer.set_pending_param_event).  Anything else that
         touches the parameters must call finish() first (densification, saving, evaluation renders do).
         Falls back to allreduce_gradients() + optimizer.step() whenever a precondition is missing."""
+        if rec is not None:
+            if rec.exchanged:
+                raise RuntimeError("this factored gradient was already exchanged (training_step(step_optimizer=False)); "
+                                   "finish the iteration with trainer.optimizer_step(gaussians)")
+            return self._factored_step(optimizer, rec)
         params = list(self.g.parameters())
         grads = [p.grad for p in params]
         active = self.world_size > 1 or self.force

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 2
+#define GSR_ABI_VERSION 3
 #define GSR_MAX_CHANNELS 64   /* widest per-pixel payload of gsr_forward / gsr_backward */
 
 typedef void* gsr_stream_t; /* hipStream_t */
@@ -59,10 +59,19 @@ enum {
                                        may make the stream wait there for SH parameters that are still being updated on
                                        another stream (pipelined data-parallel step); the geometry inputs (means, scales,
                                        rotations, opacities) must be final when gsr_forward is called */
-    GSR_FLAG_RAW_PARAMS = 8         /* opacities are logits, scales are log-scales, rotations un-normalised:
+    GSR_FLAG_RAW_PARAMS = 8,        /* opacities are logits, scales are log-scales, rotations un-normalised:
                                        the activations of scene/gaussian_model.py:37-43 (sigmoid, exp,
                                        normalize) run inside the kernels and the gradients returned are
                                        w.r.t. the raw parameters */
+    GSR_FLAG_FACTORED_SH_GRAD = 32  /* gsr_backward with `shs`: the SH gradient of one view is the outer product
+                                       basis_k(dir) x g_c of the 16 basis values of the view direction and the
+                                       clamp-masked colour gradient g = dL/drgb (utils/sh_utils.py:57-112 is linear in
+                                       the coefficients).  With this flag the [N,M,3] arrays dL_dshs / dL_dshs_rest are
+                                       NOT written (may be NULL); dL_dcolors, f32[3N + 4], receives g as [N,3] (zeros for
+                                       culled Gaussians) followed by the camera position (x, y, z, 0) -- the whole
+                                       factored gradient of the view in one contiguous record -- and
+                                       gsr_adam_sh_factored rebuilds the gradient inside the optimiser step.  48 -> 3 floats per Gaussian written, re-read and -- in the view-parallel
+                                       step -- exchanged between GPUs */
 };
 
 /* GaussianRasterizationSettings (gaussian_renderer/__init__.py:37-51) */
@@ -128,7 +137,8 @@ typedef struct GsrGrads {
                              (consumer scene/gaussian_model.py:551-553)                */
     float* dL_dopacity;   /* device [N]                                                */
     float* dL_dshs;       /* device [N,M,3] or NULL                                    */
-    float* dL_dcolors;    /* device [N,channels] or NULL (when colors_precomp was given) */
+    float* dL_dcolors;    /* device [N,channels] or NULL (when colors_precomp was given; with
+                             GSR_FLAG_FACTORED_SH_GRAD: f32[3N + 4], see the flag)  */
     float* dL_dscales;    /* device [N,2] or NULL                                      */
     float* dL_drotations; /* device [N,4] or NULL                                      */
     float* dL_dtransmat;  /* device [N,9] or NULL (when transmat_precomp was given)    */
@@ -216,6 +226,23 @@ int32_t gsr_adam_step(int32_t count, float* const* params, const float* const* g
                       float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
                       const float* step_size, const float* inv_bc2_sqrt, double beta1, double beta2,
                       double eps, gsr_stream_t stream);
+
+/* Adam step of the two SH parameter tensors (features_dc [N,1,3], features_rest [N,M-1,3]) from FACTORED gradients
+ * (GSR_FLAG_FACTORED_SH_GRAD), for the Gaussians [first, first + count):
+ *     grad[i,k,c] = grad_scale * sum_{r < n_views} basis_k( normalize(xyz[i] - campos[r]) ) * color_grad[r,i,c]
+ * with basis_k = 0 above `sh_degree` (the reference's active degree), summed in view order (reproducible).  One launch:
+ * the 48 gradient values of a Gaussian are formed in registers / LDS and never touch HBM.
+ *   xyz         device f32 [N,3]: the positions the backward saw (update xyz AFTER this call, or pass a snapshot)
+ *   color_grad  device f32 [n_views, view_stride] floats; view r's [N,3] block starts at color_grad + r * view_stride
+ *   campos      device f32 [n_views, campos_stride]; n_views <= 16
+ *   *_dc / *_rest: parameter, exp_avg, exp_avg_sq of the two tensors; step sizes as for gsr_adam_step.
+ * n_views = 1, grad_scale = 1 reproduces gsr_backward's dL_dshs followed by gsr_adam_step. */
+int32_t gsr_adam_sh_factored(int32_t first, int32_t count, int32_t sh_coeffs, int32_t sh_degree, const float* xyz,
+                             int32_t n_views, const float* color_grad, int64_t view_stride, const float* campos,
+                             int32_t campos_stride, float grad_scale,
+                             float* p_dc, float* m_dc, float* v_dc, float step_size_dc, float inv_bc2_sqrt_dc,
+                             float* p_rest, float* m_rest, float* v_rest, float step_size_rest, float inv_bc2_sqrt_rest,
+                             double beta1, double beta2, double eps, gsr_stream_t stream);
 
 /* Row compaction of the per-Gaussian tensors (pruning, scene/gaussian_model.py:398-470: `tensor[mask]` for the six
  * parameters, their Adam moments and the densification statistics).  Two calls:

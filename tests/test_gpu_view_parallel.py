@@ -33,7 +33,7 @@ def nccl_world1(gpu_device):
     dist.destroy_process_group()
 
 
-def _run(gpu_device, mode, steps=4):
+def _run(gpu_device, mode, steps=4, factored=True):
     from gaussmart_amd.gaussian_model import GaussianModel
     from gaussmart_amd.params import OptimizationParams, PipelineParams
     from gaussmart_amd.synthetic import jittered_cameras, make_scene
@@ -42,7 +42,7 @@ def _run(gpu_device, mode, steps=4):
     params, _ = make_scene(20000, 320, 200, seed=3)
     cams = jittered_cameras(steps, 320, 200, seed=1, device=gpu_device)
     gt = torch.rand(3, 200, 320, generator=torch.Generator().manual_seed(2)).to(gpu_device)
-    opt, pipe, bg = OptimizationParams(), PipelineParams(), torch.zeros(3, device=gpu_device)
+    opt, pipe, bg = OptimizationParams(), PipelineParams(factored_sh_grad=factored), torch.zeros(3, device=gpu_device)
     m = GaussianModel(3, device=gpu_device)
     m.create_from_params(params)
     m.training_setup(opt)
@@ -61,17 +61,52 @@ def _run(gpu_device, mode, steps=4):
     return [p.detach().clone() for p in m.parameters()], [float(x) for x in losses], vp
 
 
-def test_pipelined_step_equals_plain_step(gpu_device, nccl_world1):
+@pytest.mark.parametrize("factored", [True, False])
+def test_pipelined_step_equals_plain_step(gpu_device, nccl_world1, factored):
+    """factored: all-reduce of the 10 geometry floats + all-gather of the colour-gradient records (13 floats per
+    Gaussian on the wire); unfactored: all-reduce of all 58."""
     from gaussmart_amd import rasterizer
-    ref_p, ref_l, _ = _run(gpu_device, "plain")
+    ref_p, ref_l, _ = _run(gpu_device, "plain", factored=factored)
     for mode in ("flat", "pipelined"):
-        p, l, vp = _run(gpu_device, mode)
+        p, l, vp = _run(gpu_device, mode, factored=factored)
         assert l == ref_l, mode
         for a, b in zip(p, ref_p):
             assert torch.equal(a, b), mode
         assert not rasterizer._PENDING_PARAM_EVENT          # nothing left parked
         if mode == "pipelined":
             assert vp._side is not None                     # the side stream really was used
+        if factored:
+            assert vp._gathered is not None and (mode == "flat" or vp._xyz_snap is not None)
+
+
+def test_deferred_step_exchanges_in_training_step(gpu_device, nccl_world1):
+    """train()'s order -- backward + exchange, densification bookkeeping, then the optimiser step -- with the
+    factored gradient: same parameters as the immediate step."""
+    from gaussmart_amd.gaussian_model import GaussianModel
+    from gaussmart_amd.params import OptimizationParams, PipelineParams
+    from gaussmart_amd.synthetic import jittered_cameras, make_scene
+    from gaussmart_amd.trainer import optimizer_step, training_step
+    from gaussmart_amd.view_parallel import ViewParallel
+    params, _ = make_scene(8000, 200, 120, seed=6)
+    cam = jittered_cameras(1, 200, 120, seed=1, device=gpu_device)[0]
+    gt = torch.rand(3, 120, 200, generator=torch.Generator().manual_seed(2)).to(gpu_device)
+    opt, pipe, bg = OptimizationParams(), PipelineParams(), torch.zeros(3, device=gpu_device)
+    res = []
+    for deferred in (False, True):
+        m = GaussianModel(3, device=gpu_device)
+        m.create_from_params(params)
+        m.training_setup(opt)
+        vp = ViewParallel(m, force=True, pipelined=False)
+        for i in range(2):
+            training_step(m, cam, gt, opt, pipe, bg, 10000 + i, view_parallel=vp, step_optimizer=not deferred)
+            if deferred:
+                rec = m.optimizer.pending_sh[2]
+                assert rec.exchanged and rec.gathered is not None
+                optimizer_step(m)
+        torch.cuda.synchronize()
+        res.append([p.detach().clone() for p in m.parameters()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
 
 
 def test_flat_gradient_buffer_from_fused_backward(gpu_device):
@@ -86,8 +121,8 @@ def test_flat_gradient_buffer_from_fused_backward(gpu_device):
     m = GaussianModel(3, device=gpu_device)
     m.create_from_params(params)
     m.training_setup(OptimizationParams())
-    training_step(m, cam, gt, OptimizationParams(), PipelineParams(), torch.zeros(3, device=gpu_device), 10000,
-                  step_optimizer=False)
+    training_step(m, cam, gt, OptimizationParams(), PipelineParams(factored_sh_grad=False),
+                  torch.zeros(3, device=gpu_device), 10000, step_optimizer=False)
     grads = [p.grad for p in m.parameters()]
     flat = ViewParallel.flat_gradient(grads)
     assert flat is not None and flat.numel() == sum(g.numel() for g in grads) == 5000 * 58
