@@ -121,3 +121,71 @@ def test_flat_gradient_buffer_is_reduced_in_one_piece(tmp_path):
     r = [torch.load(os.path.join(tmp_path, f"flat{i}.pt"))["flat"] for i in range(world)]
     want = torch.arange(r[0].numel(), dtype=torch.float32) * 1.5      # mean of x*1 and x*2
     assert torch.equal(r[0], r[1]) and torch.allclose(r[0], want)
+
+
+def _factored_worker(rank, world, port, out_dir):
+    """The factored exchange of the view-parallel step (view_parallel.ViewParallel.exchange_factored) over gloo:
+    geometry gradients all-reduced in place, colour-gradient records all-gathered in rank order."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gaussmart_amd.rasterizer import ColorGradRecord
+    from gaussmart_amd.view_parallel import ViewParallel
+    from gaussmart_amd.sh import eval_sh
+
+    n, deg = 37, 3
+    g0 = torch.Generator().manual_seed(0)                      # replicated model
+    xyz = torch.randn(n, 3, generator=g0) * 2
+    sh = (torch.randn(n, 16, 3, generator=g0) * 0.3).requires_grad_(True)
+    gr = torch.Generator().manual_seed(10 + rank)              # this rank's view
+    campos = torch.randn(3, generator=gr) * 0.2 + torch.tensor([0.0, 0.0, -5.0])
+    upstream = torch.randn(n, 3, generator=gr)
+    upstream[rank::3] = 0.0                                    # Gaussians this view does not see
+    # explicit single-view SH gradient: autograd through the reference-parity colour function
+    d = xyz - campos
+    rgb = eval_sh(deg, sh.transpose(1, 2), d / d.norm(dim=1, keepdim=True)) + 0.5
+    mask = (rgb > 0).float()                                   # clamp_min(0) passes no gradient where it clamps
+    (torch.clamp_min(rgb, 0.0) * upstream).sum().backward()
+    # what the factored backward leaves: [geometry gradients | masked colour gradient [N,3] + camera position]
+    n_head = 10 * n + 2                                        # some padding in the head, as alignment may add
+    flat = torch.zeros(n_head + 3 * n + 4)
+    flat[:n_head] = torch.arange(n_head, dtype=torch.float32) * (rank + 1)
+    flat[n_head:n_head + 3 * n] = (upstream * mask).reshape(-1)
+    flat[n_head + 3 * n:n_head + 3 * n + 3] = campos
+    rec = ColorGradRecord(flat, flat[:n_head], flat[n_head:], n, 16, deg, xyz)
+
+    class Model:
+        def parameters(self):
+            return [xyz]
+    vp = ViewParallel(Model())
+    vp.exchange_factored(rec)
+    assert rec.exchanged and rec.n_views == world and rec.grad_scale == 1.0 / world
+    torch.save({"head": rec.head.clone(), "gathered": rec.gathered.clone(), "explicit": sh.grad.clone(),
+                "record": rec.record.clone(), "xyz": xyz}, os.path.join(out_dir, f"fact{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_factored_exchange_world2(tmp_path):
+    from gaussmart_amd.sh import sh_basis
+    world, port = 2, _free_port()
+    mp.start_processes(_factored_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    r = [torch.load(os.path.join(tmp_path, f"fact{i}.pt")) for i in range(world)]
+    n = r[0]["xyz"].shape[0]
+    stride = 3 * n + 4
+    # every rank holds the records of all ranks, in rank order, and the averaged geometry gradients
+    assert torch.equal(r[0]["gathered"], r[1]["gathered"]) and torch.equal(r[0]["head"], r[1]["head"])
+    for k in range(world):
+        assert torch.equal(r[0]["gathered"][k * stride:(k + 1) * stride], r[k]["record"])
+    want_head = torch.arange(r[0]["head"].numel(), dtype=torch.float32) * 1.5
+    assert torch.allclose(r[0]["head"], want_head)
+    # the gradient the SH optimiser step rebuilds -- mean over views of basis(dir_v) x g_v -- is the mean of the explicit
+    # single-view gradients (what an all-reduce of the [N,16,3] tensors would have delivered)
+    rebuilt = torch.zeros(n, 16, 3, dtype=torch.float64)
+    for k in range(world):
+        rec = r[0]["gathered"][k * stride:(k + 1) * stride].double()
+        g, campos = rec[:3 * n].view(n, 3), rec[3 * n:3 * n + 3]
+        d = r[0]["xyz"].double() - campos
+        rebuilt += sh_basis(3, d / d.norm(dim=1, keepdim=True))[:, :, None] * g[:, None, :] / world
+    explicit = 0.5 * (r[0]["explicit"] + r[1]["explicit"]).double()
+    assert (rebuilt - explicit).abs().max().item() <= 1e-6 * explicit.abs().max().item()
+    assert explicit.abs().max().item() > 0
