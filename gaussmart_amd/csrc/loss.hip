@@ -17,9 +17,11 @@
 #include "gsr_common.h"
 #include <cmath>
 
-#define LS_TILE 16
+#define LS_TILE 16                       // granularity of the partials array (shared with regularizer.hip)
 #define LS_HALO 5
-#define LS_REG (LS_TILE + 2 * LS_HALO)   // 26
+#define LT 32                            // pixels per side of a workgroup's tile
+#define LR (LT + 2 * LS_HALO)            // 42: tile + halo
+#define LSTR 44                          // LDS row stride of the staged planes (16-byte aligned rows)
 #define LS_C1 0.0001f
 #define LS_C2 0.0009f
 
@@ -35,159 +37,234 @@ static LossWindow make_window() {
     return win;
 }
 
-__global__ void __launch_bounds__(256) loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
+// Both kernels: one workgroup (256 threads) per 32x32 tile, channels in a loop (the next channel's tile is fetched into
+// registers while the current one is filtered).  Register-blocked separable filter:
+//   horizontal: a task = 4 consecutive outputs of one staged row: 16 inputs per plane come in with four ds_read_b128
+//               and serve 4 x 11 taps (2.75 LDS reads per output and plane instead of 11), results leave as one
+//               ds_write_b128 per filtered quantity (lane t writes floats 4t..4t+3: conflict free);
+//   vertical  : a thread = 4 consecutive rows of one column: 14 inputs serve 4 x 11 taps (3.5 reads per output), lanes
+//               of a wave read consecutive columns.
+// 16x16 tiles with one output per thread and tap-by-tap LDS reads took 84 + 74 us per step at 1080p; this: see
+// profiles/.  Partials keep their 16x16 granularity (the regularizer shares the array size): a tile adds its sums
+// to the slot of its top-left 16x16 cell and zeros the other three.
+
+// stage a 42x42 window of one plane into registers (zero padding outside the image = the reference's conv2d padding)
+#define LS_PER_THREAD ((LR * LR + 255) / 256)
+
+__device__ __forceinline__ void loss_hpass_row4(const float* __restrict__ row, const LossWindow& win, float (&in)[16]) {
+    const float4* r4 = reinterpret_cast<const float4*>(row);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float4 v = r4[i]; in[4 * i] = v.x; in[4 * i + 1] = v.y; in[4 * i + 2] = v.z; in[4 * i + 3] = v.w; }
+}
+
+__global__ void __launch_bounds__(256, 3) loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
                                                        int C, int H, int W, float* __restrict__ maps,
                                                        float* __restrict__ partials, LossWindow win) {
-    __shared__ float sx[LS_REG][LS_REG + 1], sy[LS_REG][LS_REG + 1];
-    __shared__ float sh[5][LS_REG][LS_TILE + 1];
+    __shared__ __attribute__((aligned(16))) float sx[LR][LSTR];
+    __shared__ __attribute__((aligned(16))) float sy[LR][LSTR];
+    __shared__ __attribute__((aligned(16))) float sh[5][LR][LT];
     __shared__ float red[2][4];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int x0 = blockIdx.x * LS_TILE, y0 = blockIdx.y * LS_TILE;
-    const int px = x0 + tx, py = y0 + ty;
-    const bool inside = px < W && py < H;
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
     const size_t HW = (size_t)H * W;
     float ssim_acc = 0.f, l1_acc = 0.f;
 
-    // tile + halo of one channel = 676 values per image: 3 per thread (the last pass partly idle);
-    // the NEXT channel's values are fetched into registers while the current one is filtered
-    constexpr int LS_PER_THREAD = (LS_REG * LS_REG + 255) / 256;
     float rx[LS_PER_THREAD], ry[LS_PER_THREAD];
     auto fetch = [&](int c) {
         const float* xi = img + c * HW;
         const float* yi = gt + c * HW;
 #pragma unroll
         for (int k = 0; k < LS_PER_THREAD; ++k) {
-            const int i = threadIdx.x + k * 256;
-            const int r = i / LS_REG, q = i - r * LS_REG;
+            const int i = t + k * 256;
+            const int r = i / LR, q = i - r * LR;
             const int gy = y0 + r - LS_HALO, gx = x0 + q - LS_HALO;
-            const bool ok = i < LS_REG * LS_REG && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const bool ok = i < LR * LR && gy >= 0 && gy < H && gx >= 0 && gx < W;
             rx[k] = 0.f; ry[k] = 0.f;
             if (ok) { rx[k] = xi[(size_t)gy * W + gx]; ry[k] = yi[(size_t)gy * W + gx]; }
         }
     };
     fetch(0);
+    const int vc = t & (LT - 1), vr = (t >> 5) * 4;       // vertical pass: column, first of 4 rows
     for (int c = 0; c < C; ++c) {
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < LS_PER_THREAD; ++k) {
-            const int i = threadIdx.x + k * 256;
-            if (i < LS_REG * LS_REG) { const int r = i / LS_REG, q = i - r * LS_REG; sx[r][q] = rx[k]; sy[r][q] = ry[k]; }
+            const int i = t + k * 256;
+            if (i < LR * LR) { const int r = i / LR, q = i - r * LR; sx[r][q] = rx[k]; sy[r][q] = ry[k]; }
         }
         __syncthreads();
         if (c + 1 < C) fetch(c + 1);
-        // horizontal pass: 26 rows x 16 columns
-        for (int i = threadIdx.x; i < LS_REG * LS_TILE; i += 256) {
-            const int r = i / LS_TILE, q = i - r * LS_TILE;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+        // horizontal pass: 42 rows x 8 groups of 4 outputs
+        for (int task = t; task < LR * (LT / 4); task += 256) {
+            const int r = task >> 3, s4 = (task & 7) * 4;
+            float xv[16], yv[16];
+            loss_hpass_row4(&sx[r][s4], win, xv);
+            loss_hpass_row4(&sy[r][s4], win, yv);
+            float xx[14], yy[14], xy[14];
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float w = win.w[k], xv = sx[r][q + k], yv = sy[r][q + k];
-                a0 += w * xv; a1 += w * yv; a2 += w * xv * xv; a3 += w * yv * yv; a4 += w * xv * yv;
+            for (int i = 0; i < 14; ++i) { xx[i] = xv[i] * xv[i]; yy[i] = yv[i] * yv[i]; xy[i] = xv[i] * yv[i]; }
+            float a[5][4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) {
+                    const float w = win.w[k];
+                    a0 += w * xv[o + k]; a1 += w * yv[o + k]; a2 += w * xx[o + k]; a3 += w * yy[o + k]; a4 += w * xy[o + k];
+                }
+                a[0][o] = a0; a[1][o] = a1; a[2][o] = a2; a[3][o] = a3; a[4][o] = a4;
             }
-            sh[0][r][q] = a0; sh[1][r][q] = a1; sh[2][r][q] = a2; sh[3][r][q] = a3; sh[4][r][q] = a4;
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+                *reinterpret_cast<float4*>(&sh[m][r][s4]) = make_float4(a[m][0], a[m][1], a[m][2], a[m][3]);
         }
         __syncthreads();
-        float mu1 = 0.f, mu2 = 0.f, e1 = 0.f, e2 = 0.f, e12 = 0.f;
+        // vertical pass: 4 rows of one column per thread
+        float f[5][4];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = win.w[k];
-            mu1 += w * sh[0][ty + k][tx]; mu2 += w * sh[1][ty + k][tx];
-            e1 += w * sh[2][ty + k][tx]; e2 += w * sh[3][ty + k][tx]; e12 += w * sh[4][ty + k][tx];
+        for (int m = 0; m < 5; ++m) {
+            float v[14];
+#pragma unroll
+            for (int k = 0; k < 14; ++k) v[k] = sh[m][vr + k][vc];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) acc += win.w[k] * v[o + k];
+                f[m][o] = acc;
+            }
         }
-        if (inside) {
-            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-            const float s1 = e1 - mu1_sq, s2 = e2 - mu2_sq, s12 = e12 - mu12;
-            const float A1 = 2.f * mu12 + LS_C1, A2 = 2.f * s12 + LS_C2;
-            const float B1 = mu1_sq + mu2_sq + LS_C1, B2 = s1 + s2 + LS_C2;
-            const float inv = 1.0f / (B1 * B2);
-            const float S = A1 * A2 * inv;
-            const size_t o = (size_t)py * W + px;
-            // partial derivatives with (mu1, E[x^2], E[xy]) as the independent variables
-            maps[(size_t)(0 * C + c) * HW + o] = 2.f * mu2 * (A2 - A1) * inv - 2.f * mu1 * S * (1.f / B1 - 1.f / B2);
-            maps[(size_t)(1 * C + c) * HW + o] = -S / B2;
-            maps[(size_t)(2 * C + c) * HW + o] = 2.f * A1 * inv;
-            ssim_acc += S;
-            l1_acc += fabsf(sx[ty + LS_HALO][tx + LS_HALO] - sy[ty + LS_HALO][tx + LS_HALO]);
+        const int px = x0 + vc;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int py = y0 + vr + o;
+            if (px < W && py < H) {
+                const float mu1 = f[0][o], mu2 = f[1][o], e1 = f[2][o], e2 = f[3][o], e12 = f[4][o];
+                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+                const float s1 = e1 - mu1_sq, s2 = e2 - mu2_sq, s12 = e12 - mu12;
+                const float A1 = 2.f * mu12 + LS_C1, A2 = 2.f * s12 + LS_C2;
+                const float B1 = mu1_sq + mu2_sq + LS_C1, B2 = s1 + s2 + LS_C2;
+                // ONE reciprocal (v_rcp_f32 + a Newton step: <= 1 ulp) serves 1/(B1 B2), 1/B1 = B2 inv and 1/B2 = B1 inv;
+                // four IEEE divisions here cost ~50 VALU instructions per pixel and channel
+                const float den = B1 * B2;
+                float inv = gsr_rcp(den);
+                inv = fmaf(fmaf(-den, inv, 1.0f), inv, inv);
+                const float S = A1 * A2 * inv;
+                const size_t o_ = (size_t)py * W + px;
+                // partial derivatives with (mu1, E[x^2], E[xy]) as the independent variables
+                maps[(size_t)(0 * C + c) * HW + o_] = 2.f * mu2 * (A2 - A1) * inv - 2.f * mu1 * S * ((B2 - B1) * inv);
+                maps[(size_t)(1 * C + c) * HW + o_] = -S * (B1 * inv);
+                maps[(size_t)(2 * C + c) * HW + o_] = 2.f * A1 * inv;
+                ssim_acc += S;
+                l1_acc += fabsf(sx[vr + o + LS_HALO][vc + LS_HALO] - sy[vr + o + LS_HALO][vc + LS_HALO]);
+            }
         }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { ssim_acc += __shfl_down(ssim_acc, d, 64); l1_acc += __shfl_down(l1_acc, d, 64); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ssim_acc; red[1][threadIdx.x >> 6] = l1_acc; }
+    if ((t & 63) == 0) { red[0][t >> 6] = ssim_acc; red[1][t >> 6] = l1_acc; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int b = blockIdx.y * gridDim.x + blockIdx.x;
-        partials[2 * b + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        partials[2 * b + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    if (t < 4) {
+        // the tile's sums go to the slot of its top-left 16x16 cell; the other cells it covers get zeros
+        const int g16x = (W + LS_TILE - 1) / LS_TILE, g16y = (H + LS_TILE - 1) / LS_TILE;
+        const int cx = 2 * blockIdx.x + (t & 1), cy = 2 * blockIdx.y + (t >> 1);
+        if (cx < g16x && cy < g16y) {
+            const int b = cy * g16x + cx;
+            partials[2 * b + 0] = t == 0 ? (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]) : 0.f;
+            partials[2 * b + 1] = t == 0 ? (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]) : 0.f;
+        }
     }
 }
 
-__global__ void __launch_bounds__(256) loss_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
+__global__ void __launch_bounds__(256, 3) loss_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
                                                        const float* __restrict__ maps, int C, int H, int W,
                                                        float lambda, const float* __restrict__ grad_scale,
                                                        float* __restrict__ dimg, LossWindow win) {
-    __shared__ float sm[3][LS_REG][LS_REG + 1];
-    __shared__ float sh[3][LS_REG][LS_TILE + 1];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int x0 = blockIdx.x * LS_TILE, y0 = blockIdx.y * LS_TILE;
-    const int px = x0 + tx, py = y0 + ty;
-    const bool inside = px < W && py < H;
+    __shared__ __attribute__((aligned(16))) float sm[3][LR][LSTR];
+    __shared__ __attribute__((aligned(16))) float sh[3][LR][LT];
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
     const size_t HW = (size_t)H * W;
     const float gs = grad_scale[0];
     const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
     const float k_ssim = -lambda * inv_n * gs, k_l1 = (1.0f - lambda) * inv_n * gs;
 
-    constexpr int LS_PER_THREAD = (LS_REG * LS_REG + 255) / 256;
     float rm[3][LS_PER_THREAD];
     auto fetch = [&](int c) {
 #pragma unroll
         for (int k = 0; k < LS_PER_THREAD; ++k) {
-            const int i = threadIdx.x + k * 256;
-            const int r = i / LS_REG, q = i - r * LS_REG;
+            const int i = t + k * 256;
+            const int r = i / LR, q = i - r * LR;
             const int gy = y0 + r - LS_HALO, gx = x0 + q - LS_HALO;
-            const bool ok = i < LS_REG * LS_REG && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const bool ok = i < LR * LR && gy >= 0 && gy < H && gx >= 0 && gx < W;
             const size_t o = (size_t)gy * W + gx;
 #pragma unroll
             for (int m = 0; m < 3; ++m) { rm[m][k] = 0.f; if (ok) rm[m][k] = maps[(size_t)(m * C + c) * HW + o]; }
         }
     };
     fetch(0);
+    const int vc = t & (LT - 1), vr = (t >> 5) * 4;
+    const int px = x0 + vc;
     for (int c = 0; c < C; ++c) {
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < LS_PER_THREAD; ++k) {
-            const int i = threadIdx.x + k * 256;
-            if (i < LS_REG * LS_REG) {
-                const int r = i / LS_REG, q = i - r * LS_REG;
+            const int i = t + k * 256;
+            if (i < LR * LR) {
+                const int r = i / LR, q = i - r * LR;
                 sm[0][r][q] = rm[0][k]; sm[1][r][q] = rm[1][k]; sm[2][r][q] = rm[2][k];
             }
         }
         __syncthreads();
         if (c + 1 < C) fetch(c + 1);
-        // this pixel's image / target values are only needed after both filter passes: request them now
-        float xv = 0.f, yv = 0.f;
-        if (inside) { const size_t o = (size_t)py * W + px; xv = img[c * HW + o]; yv = gt[c * HW + o]; }
-        for (int i = threadIdx.x; i < LS_REG * LS_TILE; i += 256) {
-            const int r = i / LS_TILE, q = i - r * LS_TILE;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        // this thread's image / target values are only needed after both filter passes: request them now
+        float xv[4], yv[4];
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float w = win.w[k];
-                a0 += w * sm[0][r][q + k]; a1 += w * sm[1][r][q + k]; a2 += w * sm[2][r][q + k];
+        for (int o = 0; o < 4; ++o) {
+            const int py = y0 + vr + o;
+            xv[o] = 0.f; yv[o] = 0.f;
+            if (px < W && py < H) { const size_t o_ = (size_t)py * W + px; xv[o] = img[c * HW + o_]; yv[o] = gt[c * HW + o_]; }
+        }
+        for (int task = t; task < LR * (LT / 4); task += 256) {
+            const int r = task >> 3, s4 = (task & 7) * 4;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                float in[16];
+                loss_hpass_row4(&sm[m][r][s4], win, in);
+                float a[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) acc += win.w[k] * in[o + k];
+                    a[o] = acc;
+                }
+                *reinterpret_cast<float4*>(&sh[m][r][s4]) = make_float4(a[0], a[1], a[2], a[3]);
             }
-            sh[0][r][q] = a0; sh[1][r][q] = a1; sh[2][r][q] = a2;
         }
         __syncthreads();
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        float g[3][4];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = win.w[k];
-            g0 += w * sh[0][ty + k][tx]; g1 += w * sh[1][ty + k][tx]; g2 += w * sh[2][ty + k][tx];
+        for (int m = 0; m < 3; ++m) {
+            float v[14];
+#pragma unroll
+            for (int k = 0; k < 14; ++k) v[k] = sh[m][vr + k][vc];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) acc += win.w[k] * v[o + k];
+                g[m][o] = acc;
+            }
         }
-        if (inside) {
-            const size_t o = (size_t)py * W + px;
-            const float d = xv - yv;
-            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-            dimg[c * HW + o] = k_ssim * (g0 + 2.f * xv * g1 + yv * g2) + k_l1 * sgn;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int py = y0 + vr + o;
+            if (px < W && py < H) {
+                const float d = xv[o] - yv[o];
+                const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                dimg[c * HW + (size_t)py * W + px] = k_ssim * (g[0][o] + 2.f * xv[o] * g[1][o] + yv[o] * g[2][o]) + k_l1 * sgn;
+            }
         }
     }
 }
@@ -201,7 +278,7 @@ extern "C" int32_t gsr_loss_forward(const float* img, const float* gt, int32_t C
     if (!img || !gt || !maps || !partials || C <= 0 || H <= 0 || W <= 0) { gsr_set_error("bad loss_forward arguments"); return GSR_E_INVALID; }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GsrProfileScope prof(GSR_K_LOSS_FWD, s);
-    dim3 grid((W + LS_TILE - 1) / LS_TILE, (H + LS_TILE - 1) / LS_TILE);
+    dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT);
     hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(256), 0, s, img, gt, C, H, W, maps, partials, make_window());
     GSR_LAUNCH_CHECK();
     return GSR_OK;
@@ -213,7 +290,7 @@ extern "C" int32_t gsr_loss_backward(const float* img, const float* gt, const fl
     if (!img || !gt || !maps || !grad_scale || !dimg || C <= 0 || H <= 0 || W <= 0) { gsr_set_error("bad loss_backward arguments"); return GSR_E_INVALID; }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GsrProfileScope prof(GSR_K_LOSS_BWD, s);
-    dim3 grid((W + LS_TILE - 1) / LS_TILE, (H + LS_TILE - 1) / LS_TILE);
+    dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT);
     hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, s, img, gt, maps, C, H, W, lambda_dssim, grad_scale, dimg, make_window());
     GSR_LAUNCH_CHECK();
     return GSR_OK;
