@@ -19,6 +19,7 @@ ABI_VERSION = 3
 
 GSR_BUF_GEOM, GSR_BUF_BINNING, GSR_BUF_IMAGE, GSR_BUF_SCRATCH, GSR_BUF_SCRATCH2 = range(5)
 GSR_BUF_SYNC_SH = 100     # not a buffer: "the SH colour pass is about to be enqueued" (GSR_FLAG_DEFER_COLOR)
+GSR_BUF_COLOR_STREAM = 101   # not a buffer: "a second stream for the SH colour pass?" (GSR_FLAG_DEFER_COLOR); 0 = none
 GSR_FLAG_CLAMP_PASSTHROUGH = 1
 GSR_FLAG_FILTER_DEPTH_GRAD = 2
 GSR_FLAGS_UPSTREAM = 3

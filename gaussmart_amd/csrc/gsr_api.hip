@@ -151,6 +151,15 @@ static size_t exact_rows_threshold() {
     return e && *e ? (size_t)strtoull(e, nullptr, 10) : (size_t(8) << 30);
 }
 
+// two timing-less events per calling thread for the colour pass on a second stream (created on first use and kept;
+// re-recording an event does not disturb waits that were enqueued on its previous record)
+static hipEvent_t* color_events() {
+    thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; ++i)
+        if (!ev[i] && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { ev[i] = nullptr; return nullptr; }
+    return ev;
+}
+
 static inline int bits_for(uint32_t n_values) {   // bits needed to represent 0..n_values-1
     int b = 0;
     while ((1ull << b) < n_values) ++b;
@@ -209,10 +218,29 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     void* scan_ws = static_cast<char*>(sort_ws) + sort_ws_n;
 
     const bool defer_color = (view->flags & (uint32_t)GSR_FLAG_DEFER_COLOR) != 0;
+    // colour pass on a second stream (GSR_BUF_COLOR_STREAM): whatever happens below, the call's stream ends up ordered
+    // after it, so the caller's stream-ordered buffer reuse stays safe
+    struct ColorJoin {
+        hipStream_t main; hipEvent_t done; bool armed;
+        ~ColorJoin() { if (armed) (void)hipStreamWaitEvent(main, done, 0); }
+    } color_join{s, nullptr, false};
     uint32_t D = 0;
     if (N > 0) {
         rc = gsr_launch_preprocess_fwd(*view, *g, splat, clamped, tiles_touched, tile_rect, depth_key, out->radii, s);
         if (rc != GSR_OK) return rc;
+        if (defer_color) {
+            hipStream_t cs = static_cast<hipStream_t>(alloc(ctx, GSR_BUF_COLOR_STREAM, 0));
+            if (cs && cs != s) {
+                hipEvent_t* ev2 = color_events();
+                if (!ev2) { gsr_set_error("hipEventCreate failed (colour-pass events)"); return GSR_E_HIP; }
+                GSR_HIP_CHECK(hipEventRecord(ev2[0], s));
+                GSR_HIP_CHECK(hipStreamWaitEvent(cs, ev2[0], 0));
+                rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, cs);
+                if (rc != GSR_OK) return rc;
+                GSR_HIP_CHECK(hipEventRecord(ev2[1], cs));
+                color_join.done = ev2[1]; color_join.armed = true;
+            }
+        }
         // depth order of the Gaussians (stable; culled ones carry key 0xFFFFFFFF and no tiles)
         rc = gsr_radix_sort_pairs(depth_key, nullptr, keys_sorted, order, keys_tmp, vals_tmp, N, 0, 32, sort_ws, s);
         if (rc != GSR_OK) return rc;
@@ -274,7 +302,10 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
     }
 
-    if (defer_color && N > 0) {   // binning did not need the colours: announce the pass, then enqueue it
+    if (color_join.armed) {       // the colour pass has been running on the second stream: join it here
+        color_join.armed = false;
+        GSR_HIP_CHECK(hipStreamWaitEvent(s, color_join.done, 0));
+    } else if (defer_color && N > 0) {   // binning did not need the colours: announce the pass, then enqueue it
         if (!alloc(ctx, GSR_BUF_SYNC_SH, 0)) { gsr_set_error("allocator refused GSR_BUF_SYNC_SH"); return GSR_E_ALLOC; }
         rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, s);
         if (rc != GSR_OK) return rc;

@@ -116,6 +116,7 @@ class _BufferPool:
 
 
 _POOL = _BufferPool()
+STATS = {"color_pass_on_second_stream": 0}     # how often a forward put its SH colour pass on the updater's stream
 _POOL_DEBUG = bool(__import__("os").environ.get("GSR_POOL_DEBUG"))
 
 
@@ -142,11 +143,12 @@ class _Lease:
 class _Allocator:
     """Adapter between gsr_alloc_fn and the pool for ONE library call."""
 
-    def __init__(self, device, before_color=None):
+    def __init__(self, device, before_color=None, color_stream=None):
         self.device = device
         self.buffers = {}
         self.error = None
         self.before_color = before_color        # called once, when the library announces the SH colour pass
+        self.color_stream = color_stream        # torch stream on which the SH parameters will be ready (or None)
         self.stream = torch.cuda.current_stream(device).cuda_stream
         self.kept = _Lease()        # geom / binning / image: travel with the autograd node
         self.scratch = _Lease()     # released by done()
@@ -155,6 +157,12 @@ class _Allocator:
     def _alloc(self, _ctx, which, nbytes):
         try:
             which, nbytes = int(which), max(int(nbytes), 1)
+            if which == _lib.GSR_BUF_COLOR_STREAM:   # question, not an allocation: a second stream for the colour pass?
+                if self.color_stream is None:
+                    return 0
+                self.before_color = None             # that stream is already ordered behind the parameter update
+                STATS["color_pass_on_second_stream"] += 1
+                return self.color_stream.cuda_stream
             if which == _lib.GSR_BUF_SYNC_SH:        # notification, not an allocation
                 if self.before_color is not None:
                     hook, self.before_color = self.before_color, None
@@ -202,15 +210,17 @@ def _finish_lease(ctx):
 _PENDING_PARAM_EVENT = {}
 
 
-def set_pending_param_event(device, event):
-    _PENDING_PARAM_EVENT[torch.device(device)] = event
+def set_pending_param_event(device, event, stream=None):
+    """`event`: end of the SH update; `stream`: the stream it runs on -- the next raw forward then puts its SH colour
+    pass on that stream too (GSR_BUF_COLOR_STREAM), behind the update, while its own stream sorts and bins."""
+    _PENDING_PARAM_EVENT[torch.device(device)] = (event, stream)
 
 
 def wait_pending_params(device):
     """Make the current stream wait for an outstanding side-stream parameter update (no-op if there is none)."""
-    ev = _PENDING_PARAM_EVENT.pop(torch.device(device), None)
-    if ev is not None:
-        torch.cuda.current_stream(device).wait_event(ev)
+    pend = _PENDING_PARAM_EVENT.pop(torch.device(device), None)
+    if pend is not None:
+        torch.cuda.current_stream(device).wait_event(pend[0])
 
 
 class ColorGradRecord:
@@ -399,10 +409,13 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         M = 1 + f_rest.shape[1]
         flags = int(flags) | _lib.GSR_FLAG_RAW_PARAMS
         pending = _PENDING_PARAM_EVENT.pop(torch.device(device), None)
-        hook = None
+        hook = color_stream = None
         if pending is not None:
             flags |= _lib.GSR_FLAG_DEFER_COLOR
-            hook = lambda: torch.cuda.current_stream(device).wait_event(pending)
+            pending_event, color_stream = pending
+            if color_stream is not None and color_stream == torch.cuda.current_stream(device):
+                color_stream = None
+            hook = lambda: torch.cuda.current_stream(device).wait_event(pending_event)
         rest = f_rest if f_rest.shape[1] > 0 else None
         with torch.cuda.device(device):
             view, keep = _make_view(rs, M, flags, device)
@@ -412,7 +425,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             allmap = torch.empty((7, H, W), dtype=torch.float32, device=device)
             radii = torch.empty((N,), dtype=torch.int32, device=device)
             out = _lib.GsrForwardOut(color.data_ptr(), allmap.data_ptr(), radii.data_ptr(), 0, None, None, None)
-            alloc = _Allocator(device, before_color=hook)
+            alloc = _Allocator(device, before_color=hook, color_stream=color_stream)
             stream = torch.cuda.current_stream(device).cuda_stream
             rc = L.gsr_forward(C.byref(view), C.byref(g), C.byref(out), alloc.cb, None, C.c_void_p(stream))
             alloc.done()

@@ -178,7 +178,7 @@ class ViewParallel:
             ev.record(self._side)
         rec.flat.record_stream(self._side)
         self._pending = ev
-        rasterizer.set_pending_param_event(dev, ev)
+        rasterizer.set_pending_param_event(dev, ev, self._side)
 
     def reduce_and_step(self, optimizer, rec=None):
         """all-reduce + optimiser step of one iteration.  `rec`: the factored SH gradient of this iteration's backward
@@ -244,7 +244,7 @@ class ViewParallel:
             ev.record(self._side)
         flat.record_stream(self._side)                    # its memory may be reused only after the side stream is done
         self._pending = ev
-        rasterizer.set_pending_param_event(dev, ev)
+        rasterizer.set_pending_param_event(dev, ev, self._side)
 
     def finish(self):
         """Make the current stream wait for the outstanding SH update of a pipelined step, if any."""

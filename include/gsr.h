@@ -115,7 +115,14 @@ enum { GSR_BUF_GEOM = 0, GSR_BUF_BINNING = 1, GSR_BUF_IMAGE = 2, GSR_BUF_SCRATCH
        /* not a buffer: with GSR_FLAG_DEFER_COLOR the allocator is called once with this kind and 0 bytes right before
           the SH colour pass is enqueued (the last moment the SH parameters may still be in flight on another
           stream: the callback may enqueue a stream wait); any non-NULL return value means "go on" */
-       GSR_BUF_SYNC_SH = 100 };
+       GSR_BUF_SYNC_SH = 100,
+       /* not a buffer either: with GSR_FLAG_DEFER_COLOR the allocator is first asked, with this kind and 0 bytes right
+          after the geometry pass, for a SECOND stream (hipStream_t) on which the SH parameters will be ready (e.g. the
+          stream that is still updating them).  Non-NULL: the colour pass is enqueued on that stream at once, ordered
+          after the geometry pass by an event, and only the compositing waits for it -- sorting and binning overlap the
+          parameter update AND the colour pass; GSR_BUF_SYNC_SH is then not announced.  NULL: the colour pass stays on
+          the call's stream at the late position described above */
+       GSR_BUF_COLOR_STREAM = 101 };
 
 /* Must return device memory of >= bytes, 256-byte aligned, or NULL. */
 typedef void* (*gsr_alloc_fn)(void* ctx, int32_t which, size_t bytes);

@@ -75,6 +75,7 @@ def test_pipelined_step_equals_plain_step(gpu_device, nccl_world1, factored):
         assert not rasterizer._PENDING_PARAM_EVENT          # nothing left parked
         if mode == "pipelined":
             assert vp._side is not None                     # the side stream really was used
+            assert rasterizer.STATS["color_pass_on_second_stream"] >= 3   # ... by the next forwards' colour passes too
         if factored:
             assert vp._gathered is not None and (mode == "flat" or vp._xyz_snap is not None)
 
