@@ -45,7 +45,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
     return base + inc - v;
 }
 
-__global__ void __launch_bounds__(SCAN_BLOCK) scan_reduce_kernel(const uint32_t* __restrict__ in,
+template <typename T>
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_reduce_kernel(const T* __restrict__ in,
                                                                  const uint32_t* __restrict__ gather,
                                                                  uint32_t* __restrict__ partial, int64_t n) {
     __shared__ uint32_t wt[SCAN_BLOCK / 64];
@@ -63,7 +64,8 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_reduce_kernel(const uint32_t*
     if (threadIdx.x == 0) partial[blockIdx.x] = wt[0] + wt[1] + wt[2] + wt[3];
 }
 
-__global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const uint32_t* __restrict__ in,
+template <typename T>
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const T* __restrict__ in,
                                                                 const uint32_t* __restrict__ gather,
                                                                 const uint32_t* __restrict__ partial,
                                                                 uint32_t* __restrict__ out, int64_t n) {
@@ -100,8 +102,8 @@ size_t gsr_scan_workspace_bytes(int64_t n) {
     return gsr_align(size_t(blocks > 0 ? blocks : 1) * 4);
 }
 
-int gsr_exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
-                           void* ws, hipStream_t s) {
+template <typename T>
+static int exclusive_scan_any(const T* in, const uint32_t* gather, uint32_t* out, int64_t n, void* ws, hipStream_t s) {
     if (n <= 0) {
         GSR_HIP_CHECK(hipMemsetAsync(out, 0, 4, s));
         return GSR_OK;
@@ -109,10 +111,20 @@ int gsr_exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t*
     GsrProfileScope prof(GSR_K_SCAN, s);
     uint32_t* partial = static_cast<uint32_t*>(ws);
     const int blocks = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, s, in, gather, partial, n);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, s, in, gather, partial, out, n);
+    hipLaunchKernelGGL(scan_reduce_kernel<T>, dim3(blocks), dim3(SCAN_BLOCK), 0, s, in, gather, partial, n);
+    hipLaunchKernelGGL(scan_apply_kernel<T>, dim3(blocks), dim3(SCAN_BLOCK), 0, s, in, gather, partial, out, n);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
+}
+
+int gsr_exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
+                           void* ws, hipStream_t s) {
+    return exclusive_scan_any<uint32_t>(in, gather, out, n, ws, s);
+}
+
+// same, over byte-sized inputs (the per-instance gradient-row counts, <= 16 each)
+int gsr_exclusive_scan_u8(const uint8_t* in, uint32_t* out, int64_t n, void* ws, hipStream_t s) {
+    return exclusive_scan_any<uint8_t>(in, nullptr, out, n, ws, s);
 }
 
 // ============================================================================ radix sort

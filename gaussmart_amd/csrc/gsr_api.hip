@@ -359,7 +359,7 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     const size_t sums_bytes = gsr_align(size_t(N > 0 ? N : 1) * GSR_GROW_FLOATS * 4);
     char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, cnt_bytes + slot_bytes + scan_bytes + sums_bytes));
     if (!scratch) { gsr_set_error("allocator returned NULL (backward scratch)"); return GSR_E_ALLOC; }
-    uint32_t* slot_cnt = reinterpret_cast<uint32_t*>(scratch);
+    uint8_t* slot_cnt = reinterpret_cast<uint8_t*>(scratch);
     uint32_t* slot_off = reinterpret_cast<uint32_t*>(scratch + cnt_bytes);
     void* scan_ws = scratch + cnt_bytes + slot_bytes;
     float* row_sums = reinterpret_cast<float*>(scratch + cnt_bytes + slot_bytes + scan_bytes);
@@ -369,7 +369,7 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     if (num_rendered > 0) {
         rc = gsr_launch_slot_count(num_rendered, touch, at<uint32_t>(binning, BL.inst_row), slot_cnt, s);
         if (rc != GSR_OK) return rc;
-        rc = gsr_exclusive_scan_u32(slot_cnt, nullptr, slot_off, num_rendered, scan_ws, s);
+        rc = gsr_exclusive_scan_u8(slot_cnt, slot_off, num_rendered, scan_ws, s);
         if (rc != GSR_OK) return rc;
         if (n_rows * row_bytes_each > exact_rows_threshold()) {
             uint32_t* r_host = pinned_counter();

@@ -106,6 +106,7 @@ size_t gsr_scan_workspace_bytes(int64_t n);
 // `gather` (may be NULL): in[i] is read as in[gather[i]].
 int gsr_exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
                            void* ws, hipStream_t s);
+int gsr_exclusive_scan_u8(const uint8_t* in, uint32_t* out, int64_t n, void* ws, hipStream_t s);
 size_t gsr_sort_ws_bytes(int64_t n);
 int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
                          uint32_t* vals_out, uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n,
@@ -128,7 +129,7 @@ int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float*
                           float* final_T, uint32_t* n_contrib, float* out_color,
                           float* out_allmap, uint8_t* touch, const float* feat, const uint32_t* point_list,
                           hipStream_t s);
-int gsr_launch_slot_count(int D, const uint32_t* touch, const uint32_t* inst_row, uint32_t* cnt, hipStream_t s);
+int gsr_launch_slot_count(int D, const uint32_t* touch, const uint32_t* inst_row, uint8_t* cnt, hipStream_t s);
 int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* inst_row,
                           const float* splat, const uint32_t* touch, const uint32_t* slot_off, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,

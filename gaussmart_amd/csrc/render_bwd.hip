@@ -358,14 +358,17 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
 
 // Gradient rows are dense: instance e owns rows [slot_off[e], slot_off[e + 1]), one per 4x4 block the forward
 // blended it into.  Count them per instance (touch word -> popcount, scattered to the emission index).
+// The counts (<= 16) are BYTES: the scatter is random at element granularity, and every partially written line
+// leaves the L2 as a full-line transaction -- into a D-byte array (3 MB at 1M / 1080p, L2-resident) instead of a
+// 4D-byte one that is 90 MB of HBM writes for 13 MB of payload (PMC WRITE_SIZE) less.
 __global__ void __launch_bounds__(256) slot_count_kernel(int D, const uint32_t* __restrict__ touch,
                                                          const uint32_t* __restrict__ inst_row,
-                                                         uint32_t* __restrict__ cnt) {
+                                                         uint8_t* __restrict__ cnt) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos < D) cnt[inst_row[pos]] = (uint32_t)__popc(touch[pos] & 0x0F0F0F0Fu);
+    if (pos < D) cnt[inst_row[pos]] = (uint8_t)__popc(touch[pos] & 0x0F0F0F0Fu);
 }
 
-int gsr_launch_slot_count(int D, const uint32_t* touch, const uint32_t* inst_row, uint32_t* cnt, hipStream_t s) {
+int gsr_launch_slot_count(int D, const uint32_t* touch, const uint32_t* inst_row, uint8_t* cnt, hipStream_t s) {
     if (D <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_SCAN, s);
     hipLaunchKernelGGL(slot_count_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, D, touch, inst_row, cnt);
