@@ -152,6 +152,57 @@ __device__ __forceinline__ bool gsr_rect_overlaps_quad(uint32_t wx, uint32_t wy,
     const int y0 = (int)(short)(wy & 0xFFFFu), y1 = (int)(short)(wy >> 16);
     return x0 <= bx0 + 7 && x1 >= bx0 && y0 <= by0 + 7 && y1 >= by0;
 }
+// Second, tighter stage of the quad cull (render_fwd): can the splat reach alpha >= 1/255 anywhere in the pixel box
+// [bx0, bx0+7] x [by0, by0+7]?  {alpha >= 1/255} = {rho3d <= c2} u {rho2d <= c2}, c2 = 2 ln(255 opa) (inflated like the
+// cull rect of preprocess_fwd):
+//   * {rho3d <= c2} is the screen-space image of the splat-space disc of radius sqrt(c2): an ELLIPSE with centre e and
+//     shape matrix S (the same conic that gives the rect its extents sqrt(Sxx), sqrt(Syy); the rect ignores Sxy, so
+//     for a rotated elongated splat it is mostly empty corners).  Exact box test: min over the box of
+//     (x-e)^T adj(S) (x-e) <= det S; the minimiser is the centre (inside), or lies on the box edge x = clamp(e.x) or
+//     y = clamp(e.y), where the 1-D minimum is closed form;
+//   * {rho2d <= c2} is the low-pass disc of radius sqrt(c2 / 2) around the record's centre.
+// Conservative by construction (box grown by 0.5 px + 1 % of the extents; anything degenerate or non-finite answers
+// "overlaps"), so culling stays exact: tests/test_gpu_rasterizer.py::test_wave_culling_is_exact.
+__device__ __forceinline__ bool gsr_tight_overlaps_quad(const float4 a0, const float4 a1, const float4 a2, float opa,
+                                                        int bx0, int by0) {
+    const float Tw0 = a1.z, Tw1 = a1.w, Tw2 = a2.x, cx = a2.y, cy = a2.z;
+    // pixel frame translated to the record's centre: x - cx = ((Tu - cx Tw) . h) / (Tw . h).  The ellipse centre e is
+    // then a few pixels at most and S = e e^T - M loses nothing to cancellation (in the image frame e^2 ~ 1e6 against
+    // S ~ 25 costs three digits, enough to turn the thin axis of a needle-like ellipse into noise)
+    const float Tu0 = fmaf(-cx, Tw0, a0.x), Tu1 = fmaf(-cx, Tw1, a0.y), Tu2 = fmaf(-cx, Tw2, a0.z);
+    const float Tv0 = fmaf(-cy, Tw0, a0.w), Tv1 = fmaf(-cy, Tw1, a1.x), Tv2 = fmaf(-cy, Tw2, a1.y);
+    const float c2 = (fmaxf(2.0f * __logf(255.0f * opa), 0.0f) + 0.05f) * 1.02f;
+    const float dd = c2 * (Tw0 * Tw0 + Tw1 * Tw1) - Tw2 * Tw2;
+    if (!(dd < 0.0f)) return true;
+    const float idd = gsr_rcp(dd);
+    const float g0 = c2 * idd, g2 = -idd;
+    const float ex = g0 * (Tu0 * Tw0 + Tu1 * Tw1) + g2 * Tu2 * Tw2;
+    const float ey = g0 * (Tv0 * Tw0 + Tv1 * Tw1) + g2 * Tv2 * Tw2;
+    const float Sxx = ex * ex - (g0 * (Tu0 * Tu0 + Tu1 * Tu1) + g2 * Tu2 * Tu2);
+    const float Syy = ey * ey - (g0 * (Tv0 * Tv0 + Tv1 * Tv1) + g2 * Tv2 * Tv2);
+    const float Sxy = ex * ey - (g0 * (Tu0 * Tv0 + Tu1 * Tv1) + g2 * Tu2 * Tv2);
+    const float pxy = Sxx * Syy, pdd = Sxy * Sxy;
+    const float det = pxy - pdd;
+    if (!(Sxx > 0.0f && Syy > 0.0f && det > 0.0f && pxy < 3.0e37f)) return true;
+    const float m = 0.5f + 0.01f * (sqrtf(Sxx) + sqrtf(Syy));
+    const float x0 = (float)bx0 - cx - m, x1 = (float)(bx0 + 7) - cx + m;
+    const float y0 = (float)by0 - cy - m, y1 = (float)(by0 + 7) - cy + m;
+    // ellipse vs box.  det and q are differences of products that nearly cancel for thin ellipses: a pair is culled only
+    // when q exceeds det by more than what rounding (a few 1e-7 of the products; 2e-5 is charged) could account for
+    const float lim = fmaf(2.0e-5f, pxy + pdd, det * 1.001f);
+    const float dx1 = fminf(fmaxf(ex, x0), x1) - ex;
+    const float dy1 = fminf(fmaxf(ey + Sxy * gsr_rcp(Sxx) * dx1, y0), y1) - ey;
+    const float a1_ = Syy * dx1 * dx1, b1_ = 2.0f * Sxy * dx1 * dy1, c1_ = Sxx * dy1 * dy1;
+    const bool out1 = (a1_ - b1_ + c1_) - 2.0e-5f * (a1_ + fabsf(b1_) + c1_) > lim;
+    const float dy2 = fminf(fmaxf(ey, y0), y1) - ey;
+    const float dx2 = fminf(fmaxf(ex + Sxy * gsr_rcp(Syy) * dy2, x0), x1) - ex;
+    const float a2_ = Syy * dx2 * dx2, b2_ = 2.0f * Sxy * dx2 * dy2, c2_ = Sxx * dy2 * dy2;
+    const bool out2 = (a2_ - b2_ + c2_) - 2.0e-5f * (a2_ + fabsf(b2_) + c2_) > lim;
+    // low-pass disc (centred on the record's centre = the origin of this frame) vs box
+    const float ddx = fmaxf(fmaxf(x0, -x1), 0.0f), ddy = fmaxf(fmaxf(y0, -y1), 0.0f);
+    const bool disc_out = ddx * ddx + ddy * ddy > 0.5f * c2;
+    return !(out1 && out2 && disc_out);
+}
 __device__ __forceinline__ void gsr_tile_rect(float cx, float cy, int radius, int gx, int gy,
                                               int& x0, int& y0, int& x1, int& y1) {
     // (int) casts truncate toward zero exactly like the recalled getRect

@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : 2) rend
     const int pix_id = pyi * p.W + pxi;
     const int HW = p.W * p.H;
     const bool no_cull = (p.flags & (uint32_t)GSR_FLAG_DEBUG_NO_CULL) != 0;
+    const bool tight_cull = (p.flags & (uint32_t)GSR_FLAG_DEBUG_RECT_CULL_ONLY) == 0;
 
     const uint32_t tile = (uint32_t)(tile_y * p.gx + tile_x);
     const uint32_t r0 = p.ranges[2 * tile], r1 = p.ranges[2 * tile + 1];
@@ -113,6 +114,12 @@ __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : 2) rend
     for (int base = 0; base < n_list; base += 64) {
         if (__all(done)) break;
         const int nb = min(64, n_list - base);
+        // lane l still holds the record of staged entry l: cull against this quad before the registers are recycled
+        // (rect first; the ellipse test only tightens it)
+        bool ov = false;
+        if (lane < nb)
+            ov = no_cull || (gsr_rect_overlaps_quad(__float_as_uint(pf4.z), __float_as_uint(pf4.w), qx0, qy0) &&
+                             (!tight_cull || gsr_tight_overlaps_quad(pf0, pf1, pf2, pf3.z, qx0, qy0)));
 s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_rec[lane * 5 + 3] = pf3; s_rec[lane * 5 + 4] = pf4;
         const uint32_t id_of_lane = ids_cur;
         if (!STAGE_FEAT) {   // prefetch the next batch while this one is composited
@@ -125,11 +132,6 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        bool ov = false;
-        if (lane < nb) {
-            const float4 r4 = s_rec[lane * 5 + 4];
-            ov = no_cull || gsr_rect_overlaps_quad(__float_as_uint(r4.z), __float_as_uint(r4.w), qx0, qy0);
-        }
         unsigned long long m = __ballot(ov);
         if (STAGE_FEAT) {
             // wide payload: lane l fetches the C features of staged entry l (if it survived the cull) and parks them in

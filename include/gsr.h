@@ -54,6 +54,7 @@ enum {
     GSR_FLAG_FILTER_DEPTH_GRAD = 2, /* low-pass branch: dL/dz also added to dL/dTw.x,.y times s   */
     GSR_FLAGS_UPSTREAM = 3,
     GSR_FLAG_DEBUG_NO_CULL = 4,     /* test aid: ignore the per-wave cull rect (results are bit-identical) */
+    GSR_FLAG_DEBUG_RECT_CULL_ONLY = 64, /* test / measurement aid: cull with the rect only, skip the ellipse test (same results) */
     GSR_FLAG_DEFER_COLOR = 16,      /* enqueue the SH colour pass as LATE as possible -- after binning, right before the
                                        compositing -- and announce it through the allocator (GSR_BUF_SYNC_SH): the caller
                                        may make the stream wait there for SH parameters that are still being updated on

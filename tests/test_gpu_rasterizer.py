@@ -261,19 +261,27 @@ def test_bitwise_deterministic(gpu_device):
 
 
 @pytest.mark.parametrize("n,w,h,seed,opa", [(3000, 256, 256, 0, None), (3000, 250, 130, 1, 0.999), (3000, 256, 256, 2, 0.004),
-                                             (200000, 960, 540, 3, None), (500, 256, 256, 4, None)])
+                                             (200000, 960, 540, 3, None), (500, 256, 256, 4, None),
+                                             (300000, 1600, 1200, 5, None), (300000, 1920, 1080, 6, None),
+                                             (1000000, 1920, 1080, 0, None), (20000, 3840, 2160, 7, 0.9)])
 def test_wave_culling_is_exact(gpu_device, n, w, h, seed, opa):
-    """The per-wave cull rect only skips pairs the alpha >= 1/255 test would reject anyway: outputs
-    and gradients must be BIT-identical with the culling disabled (GSR_FLAG_DEBUG_NO_CULL)."""
+    """The per-quad culls of render_fwd (pixel rect, then the exact ellipse / low-pass-disc test) only skip pairs the
+    alpha >= 1/255 test would reject anyway: outputs and gradients must be BIT-identical with the culling disabled
+    (GSR_FLAG_DEBUG_NO_CULL) and with the rect alone (GSR_FLAG_DEBUG_RECT_CULL_ONLY)."""
     from gaussmart_amd.rasterizer import GaussianRasterizer
-    p, cam = make_scene(n, w, h, seed=seed, radius_px=40.0 if seed == 4 else 6.0)
+    p, cam = make_scene(n, w, h, seed=seed, radius_px={4: 40.0, 7: 60.0}.get(seed, 6.0))
     a = _to(activate(p), gpu_device)
     if opa is not None:
         a["opacities"] = torch.full_like(a["opacities"], opa)
     if seed == 4:   # huge, strongly tilted surfels, some crossing the camera plane
         a["scales"] = a["scales"] * torch.tensor([1.0, 8.0], device=gpu_device)
+    if seed == 5:   # needles: 30:1 anisotropy at random orientations (thin axis far below a pixel)
+        a["scales"] = a["scales"] * torch.tensor([0.2, 6.0], device=gpu_device)
+    if seed == 6:   # thin slivers of every size
+        a["scales"] = a["scales"] * torch.tensor([0.02, 1.0], device=gpu_device) * \
+            torch.exp(torch.randn(n, 1, generator=torch.Generator().manual_seed(1)).to(gpu_device))
     outs = []
-    for flags in (3, 3 | 4):
+    for flags in (3, 3 | 4, 3 | 64):
         ins = {k: v.clone().requires_grad_(True) for k, v in a.items()}
         m2d = torch.zeros(n, 3, device=gpu_device, requires_grad=True)
         c, r, am = GaussianRasterizer(hip_settings(cam, 3, (0.1, 0.2, 0.3), gpu_device), flags=flags)(
@@ -281,8 +289,9 @@ def test_wave_culling_is_exact(gpu_device, n, w, h, seed, opa):
             rotations=ins["rotations"])
         (c.square().sum() + am.sum()).backward()
         outs.append([c.detach(), am.detach(), r] + [ins[k].grad for k in ins] + [m2d.grad])
-    for x, y in zip(*outs):
-        assert torch.equal(x, y)
+    for k in (1, 2):
+        for x, y in zip(outs[0], outs[k]):
+            assert torch.equal(x, y), (k, n, seed)
     assert float(outs[0][1][1].max()) > (0.0 if opa == 0.004 else 0.5)    # the scene is not trivially empty
 
 
