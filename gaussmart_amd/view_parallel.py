@@ -120,6 +120,7 @@ class ViewParallel:
                                    async_op=async_op)
         return out, work
 
+    @torch.no_grad()
     def exchange_factored(self, rec):
         """Blocking exchange of a factored backward (rasterizer.ColorGradRecord): all-reduce of the geometry gradients
         in place, all-gather of the colour-gradient records; the result is parked on `rec` for
@@ -136,6 +137,7 @@ class ViewParallel:
         rec.n_views = self.world_size
         rec.grad_scale = 1.0 / self.world_size if self.average else 1.0
 
+    @torch.no_grad()     # rec.xyz is the parameter itself: the snapshot copy must not enter an autograd graph
     def _factored_step(self, optimizer, rec):
         g = self.g
         f_dc, f_rest = g._features_dc, g._features_rest
