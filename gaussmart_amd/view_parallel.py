@@ -14,13 +14,16 @@ import torch.distributed as dist
 
 
 class ViewParallel:
-    def __init__(self, gaussians, process_group=None, average=True, force=False, pipelined=None):
+    def __init__(self, gaussians, process_group=None, average=True, force=False, pipelined=None, overlap_local=False):
         self.g = gaussians
         self.pg = process_group
         self.average = average
         self.force = force          # run the collectives even at world size 1 (single-GPU rehearsal)
         # pipelined step (RCCL + HIP only): see reduce_and_step(); GSR_DP_PIPELINE=0 switches it off
         self.pipelined = (os.environ.get("GSR_DP_PIPELINE", "1") != "0") if pipelined is None else bool(pipelined)
+        # with ONE rank and nothing to exchange, still run the factored SH update on the side stream (beside the next
+        # forward's sorting and binning)
+        self.overlap_local = bool(overlap_local)
         self._side = None           # side stream of the SH update
         self._pending = None        # event: SH update of the previous step finished
         self._gathered = None       # factored step: all-gathered colour-gradient records (grow-only)
@@ -142,42 +145,49 @@ class ViewParallel:
         g = self.g
         f_dc, f_rest = g._features_dc, g._features_rest
         stride, deg = rec.record.numel(), rec.sh_degree
-        if self.world_size == 1 and not self.force:
+        active = self.world_size > 1 or self.force          # ranks to exchange with
+        if not active and not (self.overlap_local and self.pipelined and rec.head.is_cuda):
             optimizer.step_sh_factored(f_dc, f_rest, rec.xyz, rec.record, 1, stride, deg)
             optimizer.step()
             return
         self.finish()                                     # the previous step's SH update (normally long done)
-        if not (self.pipelined and rec.head.is_cuda and dist.get_backend(self.pg) == "nccl"):
+        if active and not (self.pipelined and rec.head.is_cuda and dist.get_backend(self.pg) == "nccl"):
             self.exchange_factored(rec)
             optimizer.step_sh_factored(f_dc, f_rest, rec.xyz, rec.gathered, rec.n_views, stride, deg, rec.grad_scale)
             optimizer.step()                              # features have no .grad: skipped there
             return
         # Pipelined: the main stream waits only for the 40 MB geometry all-reduce, updates xyz / opacity / scaling /
         # rotation and starts the next forward; the all-gather of the colour gradients and the SH update run on the
-        # side stream against a snapshot of the positions, and the next forward waits for them right before its SH
-        # colour pass (rasterizer.set_pending_param_event).
+        # side stream against a snapshot of the positions, and the next forward puts its SH colour pass behind them on
+        # that stream (rasterizer.set_pending_param_event).  With `overlap_local` the same overlap is used without any
+        # exchange: the bandwidth-bound SH update runs beside the latency-bound sorting / binning of the next forward.
         from . import rasterizer
         dev = rec.head.device
-        world = self.world_size
-        op = dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM
-        w_head = dist.all_reduce(rec.head, op=op, group=self.pg, async_op=True)
-        out, w_rec = self._gather_records(rec, True)
+        w_head = w_rec = None
+        records, n_views, scale = rec.record, 1, 1.0
+        if active:
+            n_views = self.world_size
+            scale = 1.0 / n_views if self.average else 1.0
+            op = dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM
+            w_head = dist.all_reduce(rec.head, op=op, group=self.pg, async_op=True)
+            records, w_rec = self._gather_records(rec, True)
         if self._xyz_snap is None or self._xyz_snap.shape != rec.xyz.shape or self._xyz_snap.device != dev:
             self._xyz_snap = torch.empty_like(rec.xyz)
         self._xyz_snap.copy_(rec.xyz)
         snapped = torch.cuda.Event()
         snapped.record(torch.cuda.current_stream(dev))
-        w_head.wait()                                     # current stream waits for the geometry collective only
-        optimizer.step()                                  # features have no .grad: skipped
+        if w_head is not None:
+            w_head.wait()                                 # current stream waits for the geometry collective only
         if self._side is None:
             self._side = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(self._side):
             self._side.wait_event(snapped)
-            w_rec.wait()
-            optimizer.step_sh_factored(f_dc, f_rest, self._xyz_snap, out, world, stride, deg,
-                                       1.0 / world if self.average else 1.0, stream=self._side)
+            if w_rec is not None:
+                w_rec.wait()
+            optimizer.step_sh_factored(f_dc, f_rest, self._xyz_snap, records, n_views, stride, deg, scale, stream=self._side)
             ev = torch.cuda.Event()
             ev.record(self._side)
+        optimizer.step()                                  # features have no .grad: skipped
         rec.flat.record_stream(self._side)
         self._pending = ev
         rasterizer.set_pending_param_event(dev, ev, self._side)

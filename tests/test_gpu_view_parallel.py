@@ -51,6 +51,8 @@ def _run(gpu_device, mode, steps=4, factored=True):
         vp = ViewParallel(m, force=True, pipelined=True)
     elif mode == "flat":
         vp = ViewParallel(m, force=True, pipelined=False)
+    elif mode == "local":       # no exchange at all: only the side-stream SH update + colour pass
+        vp = ViewParallel(m, overlap_local=True)
     losses = []
     for i in range(steps):
         _, parts = training_step(m, cams[i], gt, opt, pipe, bg, 10000 + i, view_parallel=vp)
@@ -78,6 +80,20 @@ def test_pipelined_step_equals_plain_step(gpu_device, nccl_world1, factored):
             assert rasterizer.STATS["color_pass_on_second_stream"] >= 3   # ... by the next forwards' colour passes too
         if factored:
             assert vp._gathered is not None and (mode == "flat" or vp._xyz_snap is not None)
+
+
+def test_local_overlap_equals_plain_step(gpu_device):
+    """ViewParallel(overlap_local=True) without any process group: the factored SH update and the next forward's colour
+    pass run on the side stream; same bits as the plain step."""
+    from gaussmart_amd import rasterizer
+    ref_p, ref_l, _ = _run(gpu_device, "plain")
+    before = rasterizer.STATS["color_pass_on_second_stream"]
+    p, l, vp = _run(gpu_device, "local")
+    assert l == ref_l
+    for a, b in zip(p, ref_p):
+        assert torch.equal(a, b)
+    assert vp._side is not None and rasterizer.STATS["color_pass_on_second_stream"] >= before + 3
+    assert not rasterizer._PENDING_PARAM_EVENT
 
 
 def test_deferred_step_exchanges_in_training_step(gpu_device, nccl_world1):
