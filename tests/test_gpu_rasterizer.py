@@ -263,13 +263,17 @@ def test_bitwise_deterministic(gpu_device):
 @pytest.mark.parametrize("n,w,h,seed,opa", [(3000, 256, 256, 0, None), (3000, 250, 130, 1, 0.999), (3000, 256, 256, 2, 0.004),
                                              (200000, 960, 540, 3, None), (500, 256, 256, 4, None),
                                              (300000, 1600, 1200, 5, None), (300000, 1920, 1080, 6, None),
-                                             (1000000, 1920, 1080, 0, None), (20000, 3840, 2160, 7, 0.9)])
+                                             (1000000, 1920, 1080, 0, None), (20000, 3840, 2160, 7, 0.9),
+                                             (250000, 1237, 822, 8, None)])
 def test_wave_culling_is_exact(gpu_device, n, w, h, seed, opa):
     """The per-quad culls of render_fwd (pixel rect, then the exact ellipse / low-pass-disc test) only skip pairs the
     alpha >= 1/255 test would reject anyway: outputs and gradients must be BIT-identical with the culling disabled
     (GSR_FLAG_DEBUG_NO_CULL) and with the rect alone (GSR_FLAG_DEBUG_RECT_CULL_ONLY)."""
     from gaussmart_amd.rasterizer import GaussianRasterizer
     p, cam = make_scene(n, w, h, seed=seed, radius_px={4: 40.0, 7: 60.0}.get(seed, 6.0))
+    if seed == 8:   # off-axis view: camera moved and turned away from the canonical pose
+        from gaussmart_amd.synthetic import jittered_cameras
+        cam = jittered_cameras(4, w, h, seed=3, amount=0.6)[3]
     a = _to(activate(p), gpu_device)
     if opa is not None:
         a["opacities"] = torch.full_like(a["opacities"], opa)
