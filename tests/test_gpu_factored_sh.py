@@ -136,16 +136,16 @@ def test_factored_step_rejects_bad_arguments(gpu_device):
         opt.step_sh_factored(f_dc, f_rest, xyz, torch.zeros(17 * 34, device=gpu_device), 17, 34, 3)  # > 16 views
 
 
-def _train(gpu_device, factored, steps=5):
+def _train(gpu_device, factored, steps=5, sh_degree=3):
     from gaussmart_amd.gaussian_model import GaussianModel
     from gaussmart_amd.params import OptimizationParams, PipelineParams
     from gaussmart_amd.synthetic import jittered_cameras, make_scene
     from gaussmart_amd.trainer import training_step
-    params, _ = make_scene(20001, 320, 200, seed=3)
+    params, _ = make_scene(20001, 320, 200, seed=3, sh_degree=sh_degree)
     cams = jittered_cameras(steps, 320, 200, seed=1, device=gpu_device)
     gt = torch.rand(3, 200, 320, generator=torch.Generator().manual_seed(2)).to(gpu_device)
     opt, pipe, bg = OptimizationParams(), PipelineParams(factored_sh_grad=factored), torch.zeros(3, device=gpu_device)
-    m = GaussianModel(3, device=gpu_device)
+    m = GaussianModel(sh_degree, device=gpu_device)
     m.create_from_params(params)
     m.training_setup(opt)
     losses = [training_step(m, cams[i], gt, opt, pipe, bg, 10000 + i)[1]["total"] for i in range(steps)]
@@ -153,14 +153,20 @@ def _train(gpu_device, factored, steps=5):
     return m, [float(x) for x in losses]
 
 
-def test_training_with_factored_step_equals_unfactored(gpu_device):
-    a, la = _train(gpu_device, True)
-    b, lb = _train(gpu_device, False)
+@pytest.mark.parametrize("sh_degree", [3, 2, 1, 0])
+def test_training_with_factored_step_equals_unfactored(gpu_device, sh_degree):
+    """Models with 16, 9, 4 coefficients per channel; with 1 (degree 0) there is no features_rest and the explicit
+    path is taken."""
+    a, la = _train(gpu_device, True, sh_degree=sh_degree)
+    b, lb = _train(gpu_device, False, sh_degree=sh_degree)
     assert la[0] == lb[0]
     assert max(abs(x - y) for x, y in zip(la, lb)) <= 1e-6 * abs(lb[0])
     for name, lr in (("_xyz", 1.6e-4), ("_opacity", 0.05), ("_scaling", 0.005), ("_rotation", 0.001),
                      ("_features_dc", 0.0025), ("_features_rest", 0.0025 / 20)):
         pa, pb = getattr(a, name), getattr(b, name)
+        if pa.numel() == 0:
+            continue
         assert (pa - pb).abs().max().item() <= 0.05 * lr, name      # 5 steps of size ~lr each
         assert (pa - pb).abs().mean().item() <= 1e-4 * lr, name
     assert a._features_rest.grad is None and a.optimizer.pending_sh is None
+    assert a._features_rest.shape[1] == (sh_degree + 1) ** 2 - 1
