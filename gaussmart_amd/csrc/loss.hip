@@ -7,7 +7,7 @@
 // does the separable filtering in LDS.
 //
 // forward : per 16x16 tile and channel, stage the 26x26 neighbourhood of x and y in LDS, filter
-//           (x, y, x^2, y^2, xy) horizontally then vertically, evaluate SSIM and its partial
+//           (x, y, x^2 + y^2, xy) horizontally then vertically, evaluate SSIM and its partial
 //           derivatives w.r.t. (mu1, E[x^2], E[xy]) and write those three maps; per-block sums of
 //           SSIM and |x-y| go to a partials array (summed deterministically by the caller).
 // backward: dL/dx = -lambda/(CHW) * [ conv(dS/dmu1) + 2x conv(dS/dE[x^2]) + y conv(dS/dE[xy]) ]
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256, 3) loss_fwd_kernel(const float* __restric
                                                        float* __restrict__ partials, LossWindow win) {
     __shared__ __attribute__((aligned(16))) float sx[LR][LSTR];
     __shared__ __attribute__((aligned(16))) float sy[LR][LSTR];
-    __shared__ __attribute__((aligned(16))) float sh[5][LR][LT];
+    __shared__ __attribute__((aligned(16))) float sh[4][LR][LT];
     __shared__ float red[2][4];
     const int t = threadIdx.x;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
@@ -100,29 +100,31 @@ __global__ void __launch_bounds__(256, 3) loss_fwd_kernel(const float* __restric
             float xv[16], yv[16];
             loss_hpass_row4(&sx[r][s4], win, xv);
             loss_hpass_row4(&sy[r][s4], win, yv);
-            float xx[14], yy[14], xy[14];
+            // sigma_x^2 and sigma_y^2 enter SSIM only through their SUM (B2), and the filter is linear: ONE filtered
+            // plane x^2 + y^2 replaces E[x^2] and E[y^2] -- four planes instead of five
+            float ss[14], xy[14];
 #pragma unroll
-            for (int i = 0; i < 14; ++i) { xx[i] = xv[i] * xv[i]; yy[i] = yv[i] * yv[i]; xy[i] = xv[i] * yv[i]; }
-            float a[5][4];
+            for (int i = 0; i < 14; ++i) { ss[i] = fmaf(xv[i], xv[i], yv[i] * yv[i]); xy[i] = xv[i] * yv[i]; }
+            float a[4][4];
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 11; ++k) {
                     const float w = win.w[k];
-                    a0 += w * xv[o + k]; a1 += w * yv[o + k]; a2 += w * xx[o + k]; a3 += w * yy[o + k]; a4 += w * xy[o + k];
+                    a0 += w * xv[o + k]; a1 += w * yv[o + k]; a2 += w * ss[o + k]; a3 += w * xy[o + k];
                 }
-                a[0][o] = a0; a[1][o] = a1; a[2][o] = a2; a[3][o] = a3; a[4][o] = a4;
+                a[0][o] = a0; a[1][o] = a1; a[2][o] = a2; a[3][o] = a3;
             }
 #pragma unroll
-            for (int m = 0; m < 5; ++m)
+            for (int m = 0; m < 4; ++m)
                 *reinterpret_cast<float4*>(&sh[m][r][s4]) = make_float4(a[m][0], a[m][1], a[m][2], a[m][3]);
         }
         __syncthreads();
         // vertical pass: 4 rows of one column per thread
-        float f[5][4];
+        float f[4][4];
 #pragma unroll
-        for (int m = 0; m < 5; ++m) {
+        for (int m = 0; m < 4; ++m) {
             float v[14];
 #pragma unroll
             for (int k = 0; k < 14; ++k) v[k] = sh[m][vr + k][vc];
@@ -139,11 +141,11 @@ __global__ void __launch_bounds__(256, 3) loss_fwd_kernel(const float* __restric
         for (int o = 0; o < 4; ++o) {
             const int py = y0 + vr + o;
             if (px < W && py < H) {
-                const float mu1 = f[0][o], mu2 = f[1][o], e1 = f[2][o], e2 = f[3][o], e12 = f[4][o];
+                const float mu1 = f[0][o], mu2 = f[1][o], ess = f[2][o], e12 = f[3][o];
                 const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-                const float s1 = e1 - mu1_sq, s2 = e2 - mu2_sq, s12 = e12 - mu12;
+                const float s12 = e12 - mu12;
                 const float A1 = 2.f * mu12 + LS_C1, A2 = 2.f * s12 + LS_C2;
-                const float B1 = mu1_sq + mu2_sq + LS_C1, B2 = s1 + s2 + LS_C2;
+                const float B1 = mu1_sq + mu2_sq + LS_C1, B2 = (ess - mu1_sq - mu2_sq) + LS_C2;
                 // ONE reciprocal (v_rcp_f32 + a Newton step: <= 1 ulp) serves 1/(B1 B2), 1/B1 = B2 inv and 1/B2 = B1 inv;
                 // four IEEE divisions here cost ~50 VALU instructions per pixel and channel
                 const float den = B1 * B2;
