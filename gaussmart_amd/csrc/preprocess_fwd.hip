@@ -10,7 +10,9 @@
 // 16-byte loads into a wave-private LDS tile with 208-byte rows (conflict-free ds_read_b128 by
 // row) instead of 48 strided dword loads per lane.
 #include "gsr_common.h"
+#include <cstdlib>
 #include "sh_stage.h"
+#include "wave_reduce.h"
 
 #define PRE_BLOCK 256
 
@@ -252,6 +254,87 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_color_kernel(PreParams p
     p.clamped[idx] = clamp_bits;
 }
 
+// Colour part of K1, register-only form: 16 lanes (one DPP row) per Gaussian, lane k owns SH coefficient k.
+//   * lane k loads ITS coefficient's three channels (12 contiguous bytes; a row reads the Gaussian's 192 contiguous
+//     bytes), for four consecutive Gaussians per row before anything is consumed (3 KB per wave in flight);
+//   * every basis function of utils/sh_utils.py:57-112 has the form  C_k x^a y^b z^c (al xx + be yy + ga zz + de)
+//     with a, b, c in {0, 1}: the eight per-k constants sit in a table read once per lane, so the evaluation is
+//     branch-free and identical for all lanes (13 VALU);
+//   * the 16 products per channel are summed inside the row with four DPP steps; lane 0 stores.
+// No LDS (the staged form is limited to 12 waves per CU by its 13 KB tile per wave and spends ~300 VALU per lane
+// re-packing 45-float rows into it), no alignment requirement.  Latency-bound: per step at 1M Gaussians, geometry +
+// colour launches together, staged 0.129 ms; this form with 1 / 2 / 3 / 4 / 8 Gaussians per row and pass:
+// 0.140 / 0.119 / 0.122 / 0.124 / 0.202 ms.
+struct ShBasisRow { float C, fx, fy, fz, al, be, ga, de; };
+__constant__ ShBasisRow k_sh_basis_rows[16] = {
+    {GSR_SH_C0, 0, 0, 0, 0, 0, 0, 1},       {-GSR_SH_C1, 0, 1, 0, 0, 0, 0, 1},      {GSR_SH_C1, 0, 0, 1, 0, 0, 0, 1},
+    {-GSR_SH_C1, 1, 0, 0, 0, 0, 0, 1},      {GSR_SH_C2_0, 1, 1, 0, 0, 0, 0, 1},     {GSR_SH_C2_1, 0, 1, 1, 0, 0, 0, 1},
+    {GSR_SH_C2_2, 0, 0, 0, -1, -1, 2, 0},   {GSR_SH_C2_3, 1, 0, 1, 0, 0, 0, 1},     {GSR_SH_C2_4, 0, 0, 0, 1, -1, 0, 0},
+    {GSR_SH_C3_0, 0, 1, 0, 3, -1, 0, 0},    {GSR_SH_C3_1, 1, 1, 1, 0, 0, 0, 1},     {GSR_SH_C3_2, 0, 1, 0, -1, -1, 4, 0},
+    {GSR_SH_C3_3, 0, 0, 1, -3, -3, 2, 0},   {GSR_SH_C3_4, 1, 0, 0, -1, -1, 4, 0},   {GSR_SH_C3_5, 0, 0, 1, 1, -1, 0, 0},
+    {GSR_SH_C3_6, 1, 0, 0, 1, -3, 0, 0}};
+
+#ifndef PC_PER_ROW
+#define PC_PER_ROW 2     // Gaussians per 16-lane row and pass
+#endif
+__global__ void __launch_bounds__(PRE_BLOCK) preprocess_color16_kernel(PreParams p) {
+    const int l16 = threadIdx.x & 15;
+    const long long row = ((long long)blockIdx.x * PRE_BLOCK + threadIdx.x) >> 4;
+    const int first = (int)(row * PC_PER_ROW);
+    if (first >= p.N) return;                       // whole rows leave together (DPP stays inside a row)
+    ShBasisRow b = k_sh_basis_rows[l16];
+    const int n_active = (p.deg + 1) * (p.deg + 1);
+    if (l16 >= n_active || l16 >= p.M) b.C = 0.f;   // above the active degree: no contribution
+    const float ofx = 1.f - b.fx, ofy = 1.f - b.fy, ofz = 1.f - b.fz;
+    const float cpx = p.campos[0], cpy = p.campos[1], cpz = p.campos[2];
+
+    int radius[PC_PER_ROW];
+    float mx[PC_PER_ROW], my[PC_PER_ROW], mz[PC_PER_ROW], s0[PC_PER_ROW], s1[PC_PER_ROW], s2[PC_PER_ROW];
+#pragma unroll
+    for (int u = 0; u < PC_PER_ROW; ++u) {
+        const int idx = first + u;
+        radius[u] = 0; mx[u] = my[u] = mz[u] = 0.f; s0[u] = s1[u] = s2[u] = 0.f;
+        if (idx < p.N) {
+            radius[u] = p.radii[idx];
+            mx[u] = p.means[3 * (size_t)idx + 0]; my[u] = p.means[3 * (size_t)idx + 1]; mz[u] = p.means[3 * (size_t)idx + 2];
+            if (l16 < p.M) {
+                const float* src = p.shs_rest == nullptr ? p.shs + ((size_t)idx * p.M + l16) * 3
+                                   : (l16 == 0 ? p.shs + (size_t)idx * 3 : p.shs_rest + ((size_t)idx * (p.M - 1) + (l16 - 1)) * 3);
+                s0[u] = src[0]; s1[u] = src[1]; s2[u] = src[2];
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PC_PER_ROW; ++u) {
+        const int idx = first + u;
+        const float dx = mx[u] - cpx, dy = my[u] - cpy, dz = mz[u] - cpz;
+        const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        const float x = dx * il, y = dy * il, z = dz * il;
+        const float poly = fmaf(b.al, x * x, fmaf(b.be, y * y, fmaf(b.ga, z * z, b.de)));
+        const float mono = fmaf(b.fx, x, ofx) * fmaf(b.fy, y, ofy) * fmaf(b.fz, z, ofz);
+        const float bk = radius[u] > 0 ? b.C * mono * poly : 0.f;     // (culled: il may be anything)
+        float v[3] = {bk * s0[u], bk * s1[u], bk * s2[u]};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v[c] += dpp_move<0xB1, 0xf>(v[c]);      // quad_perm [1,0,3,2]
+            v[c] += dpp_move<0x4E, 0xf>(v[c]);      // quad_perm [2,3,0,1]
+            v[c] += dpp_move<0x141, 0xf>(v[c]);     // row_half_mirror
+            v[c] += dpp_move<0x140, 0xf>(v[c]);     // row_mirror
+        }
+        if (l16 == 0 && idx < p.N && radius[u] > 0) {
+            uint32_t clamp_bits = 0;
+            float* rec = p.splat + (size_t)idx * GSR_SPLAT_FLOATS;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float t = v[c] + 0.5f;
+                if (t < 0.0f) clamp_bits |= (1u << c);
+                rec[GSR_SP_RGB + c] = fmaxf(t, 0.0f);
+            }
+            p.clamped[idx] = clamp_bits;
+        }
+    }
+}
+
 static void fill_pre_params(PreParams& p, const GsrView& v, const GsrGaussians& g, float* splat, uint32_t* clamped,
                             uint32_t* tiles_touched, uint2* tile_rect, uint32_t* depth_key, int32_t* radii) {
     p.N = g.count; p.W = v.width; p.H = v.height;
@@ -273,7 +356,11 @@ int gsr_launch_preprocess_color(const GsrView& v, const GsrGaussians& g, float* 
     GsrProfileScope prof(GSR_K_PREPROCESS_FWD, s);
     const bool stage = sh_can_stage(g.shs, g.shs_rest, v.sh_coeffs);
     if (g.shs_rest && !stage) { gsr_set_error("split SH storage needs 16-byte aligned pointers and <= 16 coefficients"); return GSR_E_UNSUPPORTED; }
-    if (stage) {
+    if (v.sh_coeffs <= 16 && !getenv("GSR_COLOR_STAGED")) {      // (the staged form stays selectable for A/B runs)
+        const long long rows = ((long long)g.count + PC_PER_ROW - 1) / PC_PER_ROW;
+        const unsigned blocks16 = (unsigned)((rows * 16 + PRE_BLOCK - 1) / PRE_BLOCK);
+        hipLaunchKernelGGL(preprocess_color16_kernel, dim3(blocks16), dim3(PRE_BLOCK), 0, s, p);
+    } else if (stage) {
         const size_t lds_bytes = (size_t)(PRE_BLOCK / 64) * 64 * SH_ROW_FLOATS * sizeof(float);
         hipLaunchKernelGGL(preprocess_color_kernel<true>, dim3(blocks), dim3(PRE_BLOCK), lds_bytes, s, p);
     } else {
