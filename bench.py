@@ -74,6 +74,19 @@ def pmc_traffic_bytes(kernel):
         return None
 
 
+VALU_CEILING_GINST_S = 922.0   # measured: scripts/microbench/valu_rate.hip, independent wave64 v_fma_f32, whole chip
+
+
+def pmc_valu_insts(kernel):
+    """SQ_INSTS_VALU wave-instructions per launch of `kernel` from the committed PMC summary (None if not covered)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["kernels"][kernel]["valu_insts"])
+    except (OSError, KeyError, TypeError, ValueError):
+        return None
+
+
 def cpu_baseline(params, cam, n_tiles_sample, n_gauss_sample, dbg, W, H):
     """Oracle (pure PyTorch, fp32) on the host cores: preprocess on a sample of the Gaussians,
     forward+backward compositing on a sample of the frame's tiles (the frame's own tile lists),
@@ -272,6 +285,12 @@ def main():
                          "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, same scene; "
                                            "2 x FETCH_SIZE + WRITE_SIZE)",
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per_kernel[dom]},
+            # the dominant kernels are VALU-bound: the same launch priced against the MEASURED
+            # vector-issue ceiling of the chip instead of the HBM roofline (informational, not the contract's roofline)
+            "valu_issue": (lambda n: None if not n or per_kernel[dom] <= 0 else {
+                "kernel": dom, "valu_wave_insts_per_launch": n, "achieved_ginst_s": n / (per_kernel[dom] * 1e-3) / 1e9,
+                "ceiling_ginst_s": VALU_CEILING_GINST_S, "frac": n / (per_kernel[dom] * 1e-3) / 1e9 / VALU_CEILING_GINST_S,
+                "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU); ceiling: scripts/microbench/valu_rate.hip"})(pmc_valu_insts(dom)),
             "hbm_peak_gb": {"allocated": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
                             "reserved": round(torch.cuda.max_memory_reserved(dev) / 2**30, 2)},
             "reference_iter_time_ms": ref_iter_ms,    # median of the reference's fwd+loss+bwd bracket (no Adam)
