@@ -141,7 +141,7 @@ def test_render_forward_parity(gpu_device, n, w, h, seed, bg):
     assert int(((med_h != out.n_contrib[1]) & stable & (m["m_med"] > 1e-4)).sum()) == 0
 
 
-def _grad_compare(a, cam, dev, flags, bg=(0.2, 0.4, 0.6), colors=None, cov=None, seed=1):
+def _grad_compare(a, cam, dev, flags, bg=(0.2, 0.4, 0.6), colors=None, cov=None, seed=1, deg=3, scale_modifier=1.0):
     from gaussmart_amd.rasterizer import GaussianRasterizer
     N = a["means3D"].shape[0]
     W, H = cam.image_width, cam.image_height
@@ -151,13 +151,13 @@ def _grad_compare(a, cam, dev, flags, bg=(0.2, 0.4, 0.6), colors=None, cov=None,
     names = [k for k in ("means3D", "opacities", "shs", "scales", "rotations", "colors_precomp", "cov3D_precomp") if a.get(k) is not None]
     hin = {k: a[k].clone().to(dev).requires_grad_(True) for k in names}
     m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
-    rast = GaussianRasterizer(hip_settings(cam, 3, bg, dev), flags=flags)
+    rast = GaussianRasterizer(hip_settings(cam, deg, bg, dev, scale_modifier=scale_modifier), flags=flags)
     c, r, am = rast(means3D=hin["means3D"], means2D=m2d, shs=hin.get("shs"), colors_precomp=hin.get("colors_precomp"),
                     opacities=hin["opacities"], scales=hin.get("scales"), rotations=hin.get("rotations"),
                     cov3D_precomp=hin.get("cov3D_precomp"))
     ((c * wc.to(dev)).sum() + (am * wa.to(dev)).sum()).backward()
     torch.cuda.synchronize()
-    S = oracle_settings(cam, 3, torch.float64, bg)
+    S = oracle_settings(cam, deg, torch.float64, bg, scale_modifier=scale_modifier)
     oin = {k: a[k].clone().double().requires_grad_(True) for k in names}
     om2d = torch.zeros(N, 3, dtype=torch.float64, requires_grad=True)
     oc, orr, oam = O.rasterize(oin["means3D"], om2d, oin["opacities"], oin.get("shs"), oin.get("colors_precomp"),
@@ -185,6 +185,22 @@ def test_backward_parity_sh_scale_rot(gpu_device, flags):
         assert s["normwise"] < 1e-3, (k, s)
         assert s["median"] < 1e-4, (k, s)
         assert s["p99"] < 2e-3, (k, s)
+
+
+@pytest.mark.parametrize("deg,scale_modifier,view", [(3, 0.7, 0), (1, 1.0, 0), (0, 1.3, 0), (2, 1.0, 2)])
+def test_backward_parity_degree_modifier_and_view(gpu_device, deg, scale_modifier, view):
+    """Active SH degree below the stored one, scale_modifier != 1 (gaussian_renderer/__init__.py:19: scaling_modifier) and
+    an off-axis camera, against the fp64 oracle with the upstream quirk flags."""
+    p, cam = facing_scene(1500, 224, 160, seed=5)
+    if view:
+        from gaussmart_amd.synthetic import jittered_cameras
+        cam = jittered_cameras(view + 1, 224, 160, seed=4, amount=0.25)[view]
+    stats, (c_h, c_o) = _grad_compare(activate(p), cam, gpu_device, 3, deg=deg, scale_modifier=scale_modifier)
+    assert float((c_h.double() - c_o.detach()).abs().max()) < 5e-3
+    for k, s in stats.items():
+        # same median / p99 bars as above; the single worst element is a pair whose fp32 and fp64 threshold decisions
+        # differ (DESIGN.md section 2) and depends on the scene: 1e-3 ... 3.3e-3 over these four
+        assert s["normwise"] < 5e-3 and s["median"] < 1e-4 and s["p99"] < 2e-3, (k, s)
 
 
 def test_backward_parity_random_orientations(gpu_device):
