@@ -147,6 +147,8 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # the host driver of these boxes only supports dmabuf IPC; RCCL fails with hipIpcGetMemHandle otherwise
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
