@@ -155,13 +155,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if os.environ.get("GSR_BENCH_SINGLE_DEVICE"):      # rehearsal aid: every rank on cuda:0 (if the RCCL build allows it)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
     if world > 1 or under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only to rehearse the
+        if backend == "nccl":                                      # N > 1 code path with several ranks on ONE GPU
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from gaussmart_amd import _lib
     from gaussmart_amd.synthetic import make_scene, perturb, activate, jittered_cameras
