@@ -47,7 +47,9 @@ struct RenderFwdParams {
 };
 
 #ifndef RF_MIN_WAVES
-#define RF_MIN_WAVES 8   // <= 64 VGPRs: measured 0.645 -> 0.59 ms at 1M/1080p
+#define RF_MIN_WAVES 7   // <= 72 VGPRs.  With the two-stage quad cull the kernel no longer fits 64 registers without
+                         // spilling 13 dwords per lane around every batch: 8 waves 0.450 ms, 7 waves 0.424 ms, 6 waves
+                         // (79 VGPRs, no scratch at all) 0.437 ms
 #endif
 template <int CTRL>
 __device__ __forceinline__ uint32_t row_or_step(uint32_t v) {
