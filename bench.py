@@ -3,12 +3,14 @@
 
 One step = one full training iteration of the hot path over one synthetic view:
   lr update -> render() forward (HIP) -> 0.8*L1 + 0.2*(1-SSIM) + 0.05*normal loss -> backward (HIP)
-  -> [N>1: RCCL all-reduce of the per-Gaussian gradients] -> Adam step.
+  -> [N>1: RCCL exchange of the per-Gaussian gradients] -> Adam step.
 Iteration index is fixed in the 7k..30k regime of the reference schedule (train.py:132-133:
 normal loss active, SH degree 3, no densification inside the timed region).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --preset scan24|bicycle|truck        (the other BASELINE.json configs' shapes; synthetic stand-ins)
+  python bench.py --radius-px 12                       (list-length sensitivity of the headline scene)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
 kernel (timed live with HIP events on the launch stream) and `cpu_baseline` (the pure-PyTorch
@@ -27,6 +29,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+# The other BASELINE.json configurations as synthetic stand-ins (no datasets offline): Gaussian count and frame size of
+# the named scene; the mean projected 3-sigma radius is chosen so the instance count D lands in the range SURVEY 8(a) A4
+# states for it (scan24: D = 2-4 M at ~10 tiles per Gaussian; bicycle: D = 20-40 M).  "headline" is BASELINE's metric.
+PRESETS = {
+    "headline": dict(gaussians=1_000_000, width=1920, height=1080, radius_px=6.0,
+                     what="synthetic 1M-Gaussian 1920x1080 scene (SURVEY 8(d) recipe)"),
+    "scan24": dict(gaussians=300_000, width=1600, height=1200, radius_px=17.0,
+                   what="DTU scan24-like: 300k Gaussians at 1600x1200, ~10 tiles per Gaussian"),
+    "bicycle": dict(gaussians=5_000_000, width=1237, height=822, radius_px=9.0,
+                    what="Mip-NeRF360 bicycle-like: 5M Gaussians at 1237x822, D = 20-40 M"),
+    "truck": dict(gaussians=1_000_000, width=979, height=543, radius_px=6.0,
+                  what="Tanks&Temples truck-like: 1M Gaussians at 979x543 (identification/camera_loader.py:125), one view per GPU"),
+}
 
 
 def log(msg):
@@ -61,39 +77,68 @@ def iteration_bytes(N, D, P, tiles):
     return sum(b.values()) + D * 12 * (1 + 2 * npass) + N * 58 * 28
 
 
-def pmc_traffic_bytes(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (collected in separate rocprofv3 --pmc
-    passes; counters cannot be read inside this process).  gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE
-    counts half of the bytes of wide coalesced reads.  None when the summary does not cover the kernel."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+def _pmc_entry(kernel):
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            k = json.load(f)["kernels"].get(kernel)
-        return int((2.0 * k["fetch_kb"] + k["write_kb"]) * 1024) if k else None
+            return json.load(f)["kernels"].get(kernel)
     except (OSError, KeyError, TypeError, ValueError):
         return None
+
+
+# FETCH_SIZE on gfx950 reports HALF the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section) and says
+# nothing about other shapes; scripts/microbench/fetch_calib.hip measured this library's own patterns on known byte
+# counts (profiles/r02_fetch_calib.json): the factor to multiply FETCH_SIZE by is 2 for 16-B-per-lane streams AND for
+# the per-lane 80-byte record gathers / dword gathers of the compositing and binning kernels only where the calibration
+# says so.  Kernels are classed by what dominates their reads.
+FETCH_FACTOR = {"stream": 2.0, "gather": 2.0}          # overwritten from profiles/r02_fetch_calib.json when present
+KERNEL_READ_CLASS = {"render_fwd": "gather", "render_bwd": "gather", "finalize_bins": "gather", "slot_count": "gather",
+                     "reduce_rows": "stream", "preprocess_fwd": "stream", "preprocess_bwd": "stream", "adam": "stream"}
+
+
+def _load_fetch_calibration():
+    path = os.path.join(ROOT, "profiles", "r02_fetch_calib.json")
+    try:
+        with open(path) as f:
+            c = json.load(f)["fetch_factor"]
+        FETCH_FACTOR.update({k: float(v) for k, v in c.items() if k in FETCH_FACTOR})
+    except (OSError, KeyError, TypeError, ValueError):
+        pass
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (separate rocprofv3 --pmc passes; counters
+    cannot be read inside this process): raw FETCH_SIZE / WRITE_SIZE and the corrected total.  None if not covered."""
+    k = _pmc_entry(kernel)
+    if not k:
+        return None, None
+    cls = KERNEL_READ_CLASS.get(kernel, "stream")
+    raw = {"fetch_bytes_raw": int(k["fetch_kb"] * 1024), "write_bytes_raw": int(k["write_kb"] * 1024),
+           "fetch_factor": FETCH_FACTOR[cls], "read_class": cls}
+    return int(FETCH_FACTOR[cls] * k["fetch_kb"] * 1024 + k["write_kb"] * 1024), raw
 
 
 VALU_CEILING_GINST_S = 922.0   # measured: scripts/microbench/valu_rate.hip, independent wave64 v_fma_f32, whole chip
 
 
 def pmc_valu_insts(kernel):
-    """SQ_INSTS_VALU wave-instructions per launch of `kernel` from the committed PMC summary (None if not covered)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    k = _pmc_entry(kernel)
     try:
-        with open(path) as f:
-            return float(json.load(f)["kernels"][kernel]["valu_insts"])
-    except (OSError, KeyError, TypeError, ValueError):
+        return float(k["valu_insts"]) if k else None
+    except (KeyError, TypeError, ValueError):
         return None
 
 
-def cpu_baseline(params, cam, n_tiles_sample, n_gauss_sample, dbg, W, H):
-    """Oracle (pure PyTorch, fp32) on the host cores: preprocess on a sample of the Gaussians,
-    forward+backward compositing on a sample of the frame's tiles (the frame's own tile lists),
-    both scaled to the whole frame."""
+def cpu_baseline(params, cam, n_tiles_sample, n_gauss_sample, dbg, W, H, full=False):
+    """Oracle (pure PyTorch fp32 + NumPy binning) on the host cores, every stage of the iteration: preprocess forward +
+    backward, binning (duplicate + stable 64-bit sort + ranges), compositing forward + recompute-backward, L1 + SSIM loss
+    forward + backward, Adam.  By default the two expensive stages are SAMPLED (preprocess on n_gauss_sample Gaussians,
+    compositing on n_tiles_sample evenly spread tiles of the frame's own tile lists) and scaled -- about 20-30 s of host
+    work, as the bench contract asks; `full=True` (--cpu-full) runs the whole frame un-sampled (~2 min at 1M / 1080p)."""
     import numpy as np
     from oracle import surfel_ref as O
     from gaussmart_amd.synthetic import activate
+    from gaussmart_amd.losses import l1_loss, ssim
     torch.set_num_threads(host_cores())
     cores = torch.get_num_threads()
     a = {k: v.cpu() for k, v in activate(params).items()}
@@ -101,20 +146,33 @@ def cpu_baseline(params, cam, n_tiles_sample, n_gauss_sample, dbg, W, H):
     S = O.Settings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.zeros(3), 1.0,
                    cam.world_view_transform.cpu(), cam.full_proj_transform.cpu(), 3, cam.camera_center.cpu())
     # (1) per-Gaussian stage, forward + backward through autograd
-    ns = min(n_gauss_sample, N)
+    ns = N if full else min(n_gauss_sample, N)
     sub = {k: v[:ns].clone().requires_grad_(True) for k, v in a.items()}
     t0 = time.perf_counter()
     geom = O.preprocess(sub["means3D"], sub["scales"], sub["rotations"], sub["opacities"], sub["shs"], None, None, S)
     (geom.Tm.sum() + geom.xy.sum() + geom.normal.sum() + geom.rgb.sum()).backward()
     t_pre = (time.perf_counter() - t0) * (N / ns)
-    # (2) compositing, forward + recompute-backward, on evenly spread tiles of the real frame
+    # (2) binning of the whole frame (NumPy: duplicate with keys, stable sort of 64-bit keys, tile ranges)
     spl = dbg["splat"].cpu()
+    radii = dbg["radii"].cpu().numpy()
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    cx, cy, rf = spl[:, 9].numpy(), spl[:, 10].numpy(), radii.astype(np.float32)
+    t0 = time.perf_counter()
+    with np.errstate(all="ignore"):
+        tr = lambda v: np.nan_to_num(np.trunc(v / np.float32(16)), nan=0, posinf=1e9, neginf=-1e9).astype(np.int64)
+        rect = np.stack([np.clip(tr(cx - rf), 0, gx), np.clip(tr(cy - rf), 0, gy),
+                         np.clip(tr(cx + rf + np.float32(15)), 0, gx), np.clip(tr(cy + rf + np.float32(15)), 0, gy)], 1)
+    rect[radii <= 0] = 0
+    depth = dbg["depth_key"].cpu().numpy().view(np.float32)
+    keys, plist_np = O.bin_tiles(None, radii, rect.astype(np.int32), depth, gx)
+    ranges = O.tile_ranges(keys, gx * gy).astype(np.int64)
+    t_bin = time.perf_counter() - t0
+    # (3) compositing, forward + recompute-backward, on evenly spread tiles (all of them with full=True)
     gT, gxy = spl[:, 0:9].reshape(-1, 3, 3).contiguous(), spl[:, 9:11].contiguous()
     gn, go, gc = spl[:, 11:14].contiguous(), spl[:, 14].contiguous(), spl[:, 15:18].contiguous()
-    plist = dbg["point_list"].cpu().to(torch.int64)
-    ranges = dbg["ranges"].cpu().numpy().astype(np.int64)
+    plist = torch.from_numpy(plist_np.astype(np.int64))
     total_tiles = ranges.shape[0]
-    tiles = [int(i) for i in np.linspace(0, total_tiles - 1, n_tiles_sample).round()]
+    tiles = list(range(total_tiles)) if full else [int(i) for i in np.linspace(0, total_tiles - 1, n_tiles_sample).round()]
     dc, da = torch.ones(3, H, W), torch.ones(7, H, W)
     t0 = time.perf_counter()
     out = O.render_tiles(gT, gxy, gn, go, gc, plist, ranges, S, tiles=tiles)
@@ -123,10 +181,29 @@ def cpu_baseline(params, cam, n_tiles_sample, n_gauss_sample, dbg, W, H):
     inst_sample = int(sum(ranges[t, 1] - ranges[t, 0] for t in tiles))
     inst_total = int((ranges[:, 1] - ranges[:, 0]).sum())
     t_render = t_tiles * (inst_total / max(inst_sample, 1))
-    return {"value": 1.0 / (t_pre + t_render), "unit": "iters/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/surfel_ref.py fp32: preprocess fwd+bwd on {ns} of {N} Gaussians ({t_pre:.1f}s scaled) + "
-                      f"composite fwd+bwd on {len(tiles)} of {total_tiles} tiles holding {inst_sample} of {inst_total} "
-                      f"instances ({t_tiles:.1f}s measured, scaled by instances); binning, loss and Adam not included"}
+    # (4) photometric loss forward + backward (utils/loss_utils.py formulation) and (5) Adam over 58 floats per Gaussian
+    img = out.color.clone().requires_grad_(True)
+    gt = torch.rand(3, H, W)
+    t0 = time.perf_counter()
+    (0.8 * l1_loss(img, gt) + 0.2 * (1.0 - ssim(img, gt))).backward()
+    t_loss = time.perf_counter() - t0
+    p = torch.zeros(N, 58, requires_grad=True)
+    adam = torch.optim.Adam([p], lr=1e-3, eps=1e-15)
+    p.grad = torch.ones_like(p)
+    adam.step()
+    t0 = time.perf_counter()
+    adam.step()
+    t_adam = time.perf_counter() - t0
+    total = t_pre + t_bin + t_render + t_loss + t_adam
+    how = "whole frame, un-sampled" if full else \
+        (f"preprocess on {ns} of {N} Gaussians and compositing on {len(tiles)} of {total_tiles} tiles holding {inst_sample} of "
+         f"{inst_total} instances, both scaled to the frame; binning, loss and Adam on the whole frame")
+    return {"value": 1.0 / total, "unit": "iters/s", "cores": cores, "kind": "port",
+            "seconds_per_iteration": round(total, 2),
+            "stage_seconds": {"preprocess_fwd_bwd": round(t_pre, 2), "binning": round(t_bin, 2),
+                              "composite_fwd_bwd": round(t_render, 2), "loss_fwd_bwd": round(t_loss, 2), "adam": round(t_adam, 2)},
+            "sample": f"oracle/surfel_ref.py fp32 + NumPy stable sort, one full training iteration ({how}); measured host time "
+                      f"{t_pre * ns / N + t_bin + t_tiles + t_loss + t_adam:.1f} s"}
 
 
 def main():
@@ -134,12 +211,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)    # >= 200 timed iterations after 20 warm-up
     ap.add_argument("--warmup", type=int, default=20)    # (0.6 s of GPU time at 1M / 1080p)
-    ap.add_argument("--gaussians", type=int, default=1_000_000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--preset", choices=sorted(PRESETS), default="headline")
+    ap.add_argument("--gaussians", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--radius-px", type=float, default=None, help="mean projected 3-sigma radius of the synthetic splats")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tiles", type=int, default=1600)   # ~20 % of the frame: 15-20 s of host work
+    ap.add_argument("--cpu-tiles", type=int, default=1200)   # ~15 % of the frame: ~15 s of host work
+    ap.add_argument("--cpu-gaussians", type=int, default=250_000)
+    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline on the whole frame, un-sampled (~2 min)")
+    ap.add_argument("--forward-frames", type=int, default=50, help="inference frames (no_grad render) timed after the run")
     args = ap.parse_args()
+    preset = PRESETS[args.preset]
+    N = args.gaussians or preset["gaussians"]
+    W, H = args.width or preset["width"], args.height or preset["height"]
+    radius_px = args.radius_px if args.radius_px is not None else preset["radius_px"]
+    headline = (N, W, H, radius_px) == (1_000_000, 1920, 1080, 6.0)
 
     # Rank 0 must print exactly ONE line on stdout, but RCCL writes a version banner to fd 1 when the first
     # communicator is created: park the real stdout and send everything else (library chatter included) to stderr.
@@ -179,9 +266,10 @@ def main():
     from gaussmart_amd.rasterizer import rasterize_debug, GaussianRasterizationSettings
 
     _lib.lib()   # fail loudly if the HIP extension is missing
-    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(dev)}; building scene")
-    N, W, H = args.gaussians, args.width, args.height
-    params, _ = make_scene(N, W, H, seed=0, device="cpu")
+    _load_fetch_calibration()
+    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(dev)}; building scene ({args.preset}: {N} Gaussians, {W}x{H}, "
+        f"radius {radius_px} px)")
+    params, _ = make_scene(N, W, H, seed=0, device="cpu", radius_px=radius_px)
     cam = jittered_cameras(world, W, H, seed=0, device=dev)[rank]   # one view per rank
     bg = torch.zeros(3, device=dev)
     pipe, opt = PipelineParams(), OptimizationParams()
@@ -226,6 +314,23 @@ def main():
     _lib.profile_enable(False)
     warm = {k: (ms / n if n else 0.0) for k, (ms, n) in _lib.profile_read().items() if k in big}
     dom_warm = max(warm, key=warm.get) if args.warmup > 0 and any(warm.values()) else "render_bwd"
+
+    # Replica equality of the view-parallel step (every rank must hold bit-identical parameters).  The default N > 1 step
+    # is the pipelined one (collectives + SH update on side streams); should it ever leave the replicas different, the
+    # run falls back to the blocking exchange (the path the two-rank tests cover), re-synchronised from rank 0, and says so.
+    dp_path, replicas_ok_warm = None, None
+    if vp is not None and (world > 1 or force_dp):
+        dp_path = "pipelined" if vp.pipelined and dist.get_backend() == "nccl" else "blocking"
+        replicas_ok_warm = vp.replicas_identical()
+        if not replicas_ok_warm and dp_path == "pipelined":
+            log("replicas differ after the warm-up with the pipelined exchange: falling back to the blocking exchange")
+            vp.pipelined = False
+            vp.resync_from_rank0(model.optimizer)
+            dp_path = "blocking (fallback: the pipelined step left the replicas different)"
+            for i in range(max(2, args.warmup // 4)):
+                step(i)
+            torch.cuda.synchronize()
+
     log(f"timing (dominant kernel in warm-up: {dom_warm})")
     timed = _lib.KERNEL_NAMES if os.environ.get("GSR_BENCH_PROFILE_ALL") else (dom_warm,)   # all: adds event overhead
     _lib.profile_reset()
@@ -238,6 +343,7 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -245,15 +351,45 @@ def main():
     _lib.profile_enable(False)
     prof = _lib.profile_read()
     log(f"timed {args.steps} steps in {elapsed:.3f}s")
+    per_rank_ms = [local_elapsed / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([local_elapsed / args.steps * 1e3], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [float(x.item()) for x in allr]
 
-    # the reference's own `iter_time` bracket (train.py:91,145: forward + loss + backward, no optimiser step),
-    # measured AFTER the timed region with device events on a few extra steps (rank 0, informational)
-    ref_iter_ms = None
+    # ---- after the timed region (so none of this perturbs `value`) -------------------------------------------------
+    # (a) per-step times with device events: median step, and -- view-parallel runs -- how long the step's own stream
+    #     stalls on collectives (exposed communication), per step
+    n_post = min(max(args.steps, 1), 100)
+    if vp is not None:
+        vp.probe = True
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_post + 1)]
+    if world > 1:
+        dist.barrier()
+    for i in range(n_post):
+        evs[i].record()
+        step(args.warmup + args.steps + i)
+    evs[n_post].record()
+    torch.cuda.synchronize()
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_post))
+    median_ms = step_ms[n_post // 2]
+    comm_exposed_ms = comm_waits = None
+    if vp is not None:
+        exp_ms, n_waits = vp.exposed_ms()
+        comm_exposed_ms, comm_waits = exp_ms / n_post, n_waits / n_post
+        vp.probe = False
+    replicas_ok = vp.replicas_identical() if (vp is not None and (world > 1 or force_dp)) else None
+
+    # (b) the reference's own `iter_time` bracket (train.py:91,145: forward + loss + backward, no optimiser step) and
+    # (c) inference frames the way render.py / view.py produce them (render() under no_grad: forward-only kernels)
+    ref_iter_ms = fwd_fps = None
     if rank == 0:
+        if vp is not None:
+            vp.finish()
         n_ref = min(20, max(args.steps, 1))
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ref)]
         for a, b in ev:
@@ -263,6 +399,16 @@ def main():
             model.optimizer.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
         ref_iter_ms = sorted(a.elapsed_time(b) for a, b in ev)[n_ref // 2]
+        if args.forward_frames > 0:
+            with torch.no_grad():
+                for _ in range(3):
+                    render(cam, model, pipe, bg, surface_maps=False)
+                torch.cuda.synchronize()
+                tf = time.perf_counter()
+                for _ in range(args.forward_frames):
+                    render(cam, model, pipe, bg, surface_maps=False)
+                torch.cuda.synchronize()
+                fwd_fps = args.forward_frames / (time.perf_counter() - tf)
     if world > 1:
         dist.barrier()
 
@@ -276,25 +422,33 @@ def main():
         dbg = rasterize_debug(a["means3D"], a["opacities"], a["shs"], None, a["scales"], a["rotations"], None, raster_settings=rs)
         D, P = dbg["num_rendered"], W * H
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        nc = dbg["n_contrib"][0].float()
         per_kernel = {k: (ms / n if n else 0.0) for k, (ms, n) in prof.items() if k in big and n}
         dom = max(per_kernel, key=per_kernel.get)
         ab = algorithmic_bytes(N, D, P)
-        headline = (N, W, H) == (1_000_000, 1920, 1080)      # the committed PMC counters were collected on this workload
         achieved = ab[dom] / (per_kernel[dom] * 1e-3) / 1e9 if per_kernel[dom] > 0 else 0.0
         ms_per_step = elapsed / args.steps * 1e3
         iter_b = iteration_bytes(N, D, P, tiles)
+        traffic, traffic_raw = pmc_traffic(dom) if headline else (None, None)    # the committed counters are this workload's
+        metric = "train iters/sec @1M Gaussians 1080p" if (N, W, H) == (1_000_000, 1920, 1080) else \
+            f"train iters/sec @{N} Gaussians {W}x{H}"
         out = {
-            "metric": "train iters/sec @1M Gaussians 1080p", "value": world * args.steps / elapsed, "unit": "iters/s",
+            "metric": metric, "value": world * args.steps / elapsed, "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic {N}-Gaussian {W}x{H} scene (SURVEY 8(d) recipe, seed 0), SH degree 3, "
+            "config": {"workload": f"{preset['what'] if args.preset != 'headline' or headline else 'synthetic scene'}; "
+                                   f"{N} Gaussians, {W}x{H}, mean projected radius {radius_px} px, seed 0, SH degree 3, "
                                    f"L1+SSIM+normal loss, Adam; one view per GPU per step",
-                       "gaussians": N, "width": W, "height": H, "instances_D": D,
+                       "preset": args.preset, "gaussians": N, "width": W, "height": H, "radius_px": radius_px, "instances_D": D,
+                       "tile_list_mean": round(D / tiles, 1), "entries_walked_per_pixel_mean": round(float(nc.mean()), 1),
+                       "entries_walked_per_pixel_max": int(nc.max()),
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU"},
+            "ms_per_step_median": median_ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(dom) if headline else None,
-                         "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, same scene; "
-                                           "2 x FETCH_SIZE + WRITE_SIZE)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw,
+                         "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, same scene): "
+                                           "fetch_factor x FETCH_SIZE + WRITE_SIZE, factor per read class calibrated on known "
+                                           "byte counts (profiles/r02_fetch_calib.json, scripts/microbench/fetch_calib.hip)",
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per_kernel[dom]},
             # the dominant kernels are VALU-bound: the same launch priced against the MEASURED
             # vector-issue ceiling of the chip instead of the HBM roofline (informational, not the contract's roofline)
@@ -306,14 +460,24 @@ def main():
             "hbm_peak_gb": {"allocated": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
                             "reserved": round(torch.cuda.max_memory_reserved(dev) / 2**30, 2)},
             "reference_iter_time_ms": ref_iter_ms,    # median of the reference's fwd+loss+bwd bracket (no Adam)
+            "forward_only_fps": fwd_fps,              # render() under no_grad (render.py / view.py), this frame
             "kernel_ms": {k: round(v, 4) for k, v in per_kernel.items()},
             "kernel_ms_warmup": {k: round(v, 4) for k, v in warm.items()},
             "kernel_ms_per_step": {k: round(ms / args.steps, 4) for k, (ms, n) in prof.items() if n},
             "iteration": {"algorithmic_bytes": iter_b, "hbm_frac": iter_b / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        if vp is not None and (world > 1 or force_dp):
+            out["view_parallel"] = {"path": dp_path, "comm_exposed_ms_per_step": comm_exposed_ms,
+                                    "collective_waits_per_step": comm_waits,
+                                    "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
+                                    "replicas_identical_after_warmup": replicas_ok_warm,
+                                    "replicas_identical_after_run": replicas_ok,
+                                    "exchange": "40 B/Gaussian all-reduced (geometry) + 12 B/Gaussian/peer all-gathered "
+                                                "(factored SH colour gradients)" if pipe.factored_sh_grad else
+                                                "232 B/Gaussian all-reduced"}
         if world == 1 and not args.no_cpu_baseline:
             log(f"GPU part done ({out['value']:.2f} it/s, D={D}); timing the CPU oracle on {host_cores()} cores")
-            out["cpu_baseline"] = cpu_baseline(params, cam, args.cpu_tiles, N, dbg, W, H)
+            out["cpu_baseline"] = cpu_baseline(params, cam, args.cpu_tiles, args.cpu_gaussians, dbg, W, H, full=args.cpu_full)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():

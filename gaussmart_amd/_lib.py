@@ -27,6 +27,7 @@ GSR_FLAG_DEBUG_NO_CULL = 4
 GSR_FLAG_RAW_PARAMS = 8
 GSR_FLAG_DEFER_COLOR = 16
 GSR_FLAG_DEBUG_RECT_CULL_ONLY = 64
+GSR_FLAG_FORWARD_ONLY = 128      # inference: keep nothing for a backward (no touch words, no per-pixel state)
 GSR_FLAG_FACTORED_SH_GRAD = 32   # backward writes the masked colour gradient [N,3] instead of the SH gradient arrays
 
 KERNEL_NAMES = ("preprocess_fwd", "sort_hist", "sort_scatter", "scan", "emit_instances",

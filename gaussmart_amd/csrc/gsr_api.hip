@@ -24,7 +24,7 @@ extern "C" int32_t gsr_abi_version(void) { return GSR_ABI_VERSION; }
 namespace {
 struct KernelProf {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-    hipEvent_t open = nullptr;
+    std::vector<std::pair<hipStream_t, hipEvent_t>> open;   // one open bracket per stream (two models / two streams per device)
     double total_ms = 0.0;
     int launches = 0;
 };
@@ -56,21 +56,25 @@ void gsr_profile_begin(int kernel, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!((g_prof_mask >> kernel) & 1u)) return;
     KernelProf& k = g_prof[kernel];
-    if (k.pending.size() >= kMaxPending || k.open) return;
+    if (k.pending.size() >= kMaxPending) return;
+    for (auto& o : k.open) if (o.first == s) return;      // (a bracket of this kernel is already open on this stream)
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, s);
-    k.open = e;
+    k.open.emplace_back(s, e);
 }
 void gsr_profile_end(int kernel, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     KernelProf& k = g_prof[kernel];
-    if (!k.open) return;
-    hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) { (void)hipEventDestroy(k.open); k.open = nullptr; return; }
-    (void)hipEventRecord(e, s);
-    k.pending.emplace_back(k.open, e);
-    k.open = nullptr;
+    for (size_t i = 0; i < k.open.size(); ++i) {
+        if (k.open[i].first != s) continue;
+        hipEvent_t b = k.open[i].second, e;
+        k.open.erase(k.open.begin() + (long)i);
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipEventDestroy(b); return; }
+        (void)hipEventRecord(e, s);
+        k.pending.emplace_back(b, e);
+        return;
+    }
 }
 extern "C" void gsr_profile_enable(int32_t mask) { g_prof_mask = (uint32_t)mask; }
 extern "C" void gsr_profile_reset(void) {
@@ -188,9 +192,10 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
 
     const GsrGeomLayout GL(N);
     const GsrImageLayout IL(P);
+    const bool fwd_only = (view->flags & (uint32_t)GSR_FLAG_FORWARD_ONLY) != 0 && view->channels == 3;
     void* geom = alloc(ctx, GSR_BUF_GEOM, GL.total);
-    void* image = alloc(ctx, GSR_BUF_IMAGE, IL.total);
-    if (!geom || !image) { gsr_set_error("allocator returned NULL (geom/image)"); return GSR_E_ALLOC; }
+    void* image = fwd_only ? nullptr : alloc(ctx, GSR_BUF_IMAGE, IL.total);
+    if (!geom || (!image && !fwd_only)) { gsr_set_error("allocator returned NULL (geom/image)"); return GSR_E_ALLOC; }
     out->geom = geom; out->image = image; out->binning = nullptr; out->num_rendered = 0;
 
     float* splat = at<float>(geom, GL.splat);
@@ -310,8 +315,8 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, s);
         if (rc != GSR_OK) return rc;
     }
-    return gsr_launch_render_fwd(*view, ranges, splat, at<float>(image, IL.final_T),
-                                 at<uint32_t>(image, IL.n_contrib), out->out_color, out->out_allmap,
+    return gsr_launch_render_fwd(*view, ranges, splat, fwd_only ? nullptr : at<float>(image, IL.final_T),
+                                 fwd_only ? nullptr : at<uint32_t>(image, IL.n_contrib), out->out_color, out->out_allmap,
                                  at<uint8_t>(binning, BL.touch), view->channels == 3 ? nullptr : g->colors_precomp,
                                  point_list, s);
 }
@@ -332,6 +337,10 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
         (g->scales && (!grads->dL_dscales || !grads->dL_drotations)) ||
         (g->transmat_precomp && !grads->dL_dtransmat)) {
         gsr_set_error("backward inputs / gradient outputs missing");
+        return GSR_E_INVALID;
+    }
+    if (view->flags & (uint32_t)GSR_FLAG_FORWARD_ONLY) {
+        gsr_set_error("gsr_backward called for a GSR_FLAG_FORWARD_ONLY forward: nothing was kept for it");
         return GSR_E_INVALID;
     }
     hipStream_t s = static_cast<hipStream_t>(stream_);

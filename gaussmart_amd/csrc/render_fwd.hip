@@ -59,7 +59,10 @@ __device__ __forceinline__ uint32_t row_or_step(uint32_t v) {
 // FEAT16 = 0: three colour channels taken from the splat record (the reference's configuration).
 // FEAT16 = 1..4: up to 16*FEAT16 feature channels read from `feat` [N,C] by Gaussian id, staged per batch in a
 // wave-private LDS tile (wide per-pixel payload); everything else is identical.
-template <int FEAT16>
+// SAVE = false: forward-only rendering (render.py / view.py under torch.no_grad(); utils/mesh_utils.py:100-123): no
+// touch bytes, no per-pixel state for a backward that will never run -- the mask bookkeeping, four DPP OR steps and
+// eight readlanes per batch and 20 of the 60 bytes written per pixel disappear.
+template <int FEAT16, bool SAVE>
 __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : 2) render_fwd_kernel(RenderFwdParams p) {
     __shared__ float4 s_rec_all[RF_WAVES][64 * 5];
     // wide payload: the features of the staged entries that survive the cull, [entry][channel], wave-private
@@ -198,9 +201,15 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
                 }
             }
             T = test_T;
-            last_contributor = contributor;
-            const unsigned long long bit = 1ull << j;          // wave-uniform (scalar shift)
-            mine_lo |= (uint32_t)bit; mine_hi |= (uint32_t)(bit >> 32);
+            if (SAVE) {
+                last_contributor = contributor;
+                const unsigned long long bit = 1ull << j;          // wave-uniform (scalar shift)
+                mine_lo |= (uint32_t)bit; mine_hi |= (uint32_t)(bit >> 32);
+            }
+        }
+        if (!SAVE) {
+            __builtin_amdgcn_wave_barrier();   // all reads of this batch precede the next batch's LDS writes
+            continue;
         }
         // OR over the 16 pixels of each 4x4 block (DPP inside a row), once per batch: which staged splats did
         // this block blend at all?
@@ -224,14 +233,17 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
 
     // entries behind the point where every pixel saturated were never staged: nothing was blended there
     // (the backward sizes its gradient rows from these bytes, so they must all be defined)
-    for (int pos = covered + lane; pos < n_list; pos += 64) p.touch[((size_t)r0 + pos) * 4 + wave] = 0;
+    if (SAVE)
+        for (int pos = covered + lane; pos < n_list; pos += 64) p.touch[((size_t)r0 + pos) * 4 + wave] = 0;
 
     if (inside) {
-        p.final_T[pix_id] = T;
-        p.final_T[pix_id + HW] = M1;
-        p.final_T[pix_id + 2 * HW] = M2;
-        p.n_contrib[pix_id] = last_contributor;
-        p.n_contrib[pix_id + HW] = med_contrib;
+        if (SAVE) {
+            p.final_T[pix_id] = T;
+            p.final_T[pix_id + HW] = M1;
+            p.final_T[pix_id + 2 * HW] = M2;
+            p.n_contrib[pix_id] = last_contributor;
+            p.n_contrib[pix_id + HW] = med_contrib;
+        }
         if (FEAT16 == 0) {
             p.out_color[pix_id] = C0 + T * p.bg[0];
             p.out_color[pix_id + HW] = C1 + T * p.bg[1];
@@ -266,13 +278,14 @@ int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float*
     p.n_tiles = p.gx * gy; p.per_xcd = (p.n_tiles + 7) / 8;
     const dim3 grid(8 * p.per_xcd), block(RF_BLOCK);
     if (feat == nullptr) {
-        hipLaunchKernelGGL(render_fwd_kernel<0>, grid, block, 0, s, p);
+        if (v.flags & (uint32_t)GSR_FLAG_FORWARD_ONLY) hipLaunchKernelGGL((render_fwd_kernel<0, false>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((render_fwd_kernel<0, true>), grid, block, 0, s, p);
     } else {
-        switch ((v.channels + 15) / 16) {
-            case 1: hipLaunchKernelGGL(render_fwd_kernel<1>, grid, block, 0, s, p); break;
-            case 2: hipLaunchKernelGGL(render_fwd_kernel<2>, grid, block, 0, s, p); break;
-            case 3: hipLaunchKernelGGL(render_fwd_kernel<3>, grid, block, 0, s, p); break;
-            case 4: hipLaunchKernelGGL(render_fwd_kernel<4>, grid, block, 0, s, p); break;
+        switch ((v.channels + 15) / 16) {   // (wide payloads always keep the backward state)
+            case 1: hipLaunchKernelGGL((render_fwd_kernel<1, true>), grid, block, 0, s, p); break;
+            case 2: hipLaunchKernelGGL((render_fwd_kernel<2, true>), grid, block, 0, s, p); break;
+            case 3: hipLaunchKernelGGL((render_fwd_kernel<3, true>), grid, block, 0, s, p); break;
+            case 4: hipLaunchKernelGGL((render_fwd_kernel<4, true>), grid, block, 0, s, p); break;
             default: gsr_set_error("wide payload supports at most 64 channels"); return GSR_E_UNSUPPORTED;
         }
     }

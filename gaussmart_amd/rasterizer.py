@@ -207,20 +207,42 @@ def _finish_lease(ctx):
 # forward lets its geometry / binning phase run and makes the stream wait right before the SH colour pass
 # (GSR_FLAG_DEFER_COLOR: the pass is enqueued after binning, announced through the allocator); every other consumer
 # waits up front.
-_PENDING_PARAM_EVENT = {}
+_PENDING_PARAM_EVENT = {}     # (device, model key) -> (event, stream); model key = data_ptr of the model's xyz parameter
 
 
-def set_pending_param_event(device, event, stream=None):
-    """`event`: end of the SH update; `stream`: the stream it runs on -- the next raw forward then puts its SH colour
-    pass on that stream too (GSR_BUF_COLOR_STREAM), behind the update, while its own stream sorts and bins."""
-    _PENDING_PARAM_EVENT[torch.device(device)] = (event, stream)
+def _model_key(xyz):
+    """Identity of a model for the module-level hand-over slots: the storage address of its position parameter (two
+    models on one device never share it; a densification that replaces the tensor also retires the stale slot)."""
+    return None if xyz is None else int(xyz.data_ptr())
 
 
-def wait_pending_params(device):
-    """Make the current stream wait for an outstanding side-stream parameter update (no-op if there is none)."""
-    pend = _PENDING_PARAM_EVENT.pop(torch.device(device), None)
-    if pend is not None:
-        torch.cuda.current_stream(device).wait_event(pend[0])
+def set_pending_param_event(device, event, stream=None, model=None):
+    """`event`: end of the SH update; `stream`: the stream it runs on -- the next raw forward OF THAT MODEL (`model` =
+    its xyz parameter) then puts its SH colour pass on that stream too (GSR_BUF_COLOR_STREAM), behind the update, while
+    its own stream sorts and bins.  Forwards of other models on the same device are not affected."""
+    _PENDING_PARAM_EVENT[(torch.device(device), _model_key(model))] = (event, stream)
+
+
+def _pop_pending(device, model):
+    device = torch.device(device)
+    pend = _PENDING_PARAM_EVENT.pop((device, _model_key(model)), None)
+    if pend is None and model is not None:       # parked without a model key (legacy callers): belongs to whoever runs next
+        pend = _PENDING_PARAM_EVENT.pop((device, None), None)
+    return pend
+
+
+def wait_pending_params(device, model=None):
+    """Make the current stream wait for outstanding side-stream parameter updates (no-op if there are none): the one
+    of `model` (its xyz parameter), or -- without a model, for callers that only hold derived tensors -- every update
+    pending on the device."""
+    device = torch.device(device)
+    if model is not None:
+        pend = _pop_pending(device, model)
+        if pend is not None:
+            torch.cuda.current_stream(device).wait_event(pend[0])
+        return
+    for key in [k for k in _PENDING_PARAM_EVENT if k[0] == device]:
+        torch.cuda.current_stream(device).wait_event(_PENDING_PARAM_EVENT.pop(key)[0])
 
 
 class ColorGradRecord:
@@ -239,12 +261,18 @@ class ColorGradRecord:
         self.exchanged, self.gathered, self.n_views, self.grad_scale = False, None, 1, 1.0
 
 
-_COLOR_GRAD = {}
+_COLOR_GRAD = {}     # (device, model key) -> ColorGradRecord of that model's last factored backward
 
 
-def take_color_grad(device):
-    """The ColorGradRecord the last factored backward on `device` left (None if there was none); clears the slot."""
-    return _COLOR_GRAD.pop(torch.device(device), None)
+def take_color_grad(model_or_device):
+    """The ColorGradRecord the last factored backward left (None if there was none); clears the slot.  Pass the model's
+    xyz parameter: records are kept per model, so two models training on one device do not see each other's.  A device
+    (legacy) returns the most recent record on it."""
+    if isinstance(model_or_device, torch.Tensor):
+        return _COLOR_GRAD.pop((model_or_device.device, _model_key(model_or_device)), None)
+    device = torch.device(model_or_device)
+    keys = [k for k in _COLOR_GRAD if k[0] == device]
+    return _COLOR_GRAD.pop(keys[-1], None) if keys else None
 
 
 def release_workspace():
@@ -408,7 +436,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             raise ValueError("features_dc must be [N,1,3] and features_rest [N,K-1,3]")
         M = 1 + f_rest.shape[1]
         flags = int(flags) | _lib.GSR_FLAG_RAW_PARAMS
-        pending = _PENDING_PARAM_EVENT.pop(torch.device(device), None)
+        pending = _pop_pending(device, xyz)
         hook = color_stream = None
         if pending is not None:
             flags |= _lib.GSR_FLAG_DEFER_COLOR
@@ -497,8 +525,41 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         del keep
         _finish_lease(ctx)
         if factored:
-            _COLOR_GRAD[torch.device(device)] = ColorGradRecord(flat, flat[:n_head], record, N, ctx.M, rs.sh_degree, xyz)
+            _COLOR_GRAD[(torch.device(device), _model_key(xyz))] = ColorGradRecord(flat, flat[:n_head], record, N, ctx.M,
+                                                                                   rs.sh_degree, xyz)
         return d_xyz, d_2d, d_dc, d_rest, d_op, d_sc, d_rot, None, None
+
+
+def _wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _forward_only(device, rs, flags, sh_coeffs, gaussians_args, N):
+    """Inference path (render.py / view.py / GaussianExtractor under torch.no_grad(): utils/mesh_utils.py:100-123,
+    view.py:15-31): GSR_FLAG_FORWARD_ONLY -- no touch words, no per-pixel state, no autograd node, and every library
+    buffer goes back to the pool as soon as the call has been enqueued (stream-ordered reuse)."""
+    L = _lib.lib()
+    if device.type != "cuda":
+        raise _lib.GsrError("GaussianRasterizer needs tensors on a HIP device (torch 'cuda'); there is no CPU path")
+    wait_pending_params(device)
+    H, W = int(rs.image_height), int(rs.image_width)
+    with torch.cuda.device(device):
+        view, keep = _make_view(rs, sh_coeffs, int(flags) | _lib.GSR_FLAG_FORWARD_ONLY, device)
+        g = _lib.GsrGaussians(N, *[_ptr(a) for a in gaussians_args])
+        color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+        allmap = torch.empty((7, H, W), dtype=torch.float32, device=device)
+        radii = torch.empty((N,), dtype=torch.int32, device=device)
+        out = _lib.GsrForwardOut(color.data_ptr(), allmap.data_ptr(), radii.data_ptr(), 0, None, None, None)
+        alloc = _Allocator(device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        rc = L.gsr_forward(C.byref(view), C.byref(g), C.byref(out), alloc.cb, None, C.c_void_p(stream))
+        alloc.done()
+        alloc.kept.release()
+        if rc != 0 and alloc.error is not None:
+            raise alloc.error
+        _lib.check(rc)
+    del keep
+    return color, radii, allmap
 
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
@@ -507,6 +568,16 @@ def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_ra
     `factored_sh_grad`: the backward leaves NO gradient on features_dc / features_rest; it parks a ColorGradRecord
     (take_color_grad) for FusedAdam.step_sh_factored instead -- only for callers that own the optimiser step."""
     flags = DEFAULT_FLAGS if flags is None else flags
+    if not _wants_grad(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw):
+        device = xyz.device
+        args = [_f32c(t, n, device) for t, n in ((xyz, "xyz"), (features_dc, "features_dc"), (None, ""), (opacity_raw, "opacity"),
+                                                 (scaling_raw, "scaling"), (rotation_raw, "rotation"), (None, ""))]
+        rest = _f32c(features_rest, "features_rest", device)
+        if args[1].dim() != 3 or args[1].shape[1] != 1 or rest.dim() != 3 or rest.shape[0] != xyz.shape[0]:
+            raise ValueError("features_dc must be [N,1,3] and features_rest [N,K-1,3]")
+        args.append(rest if rest.shape[1] > 0 else None)
+        return _forward_only(device, raster_settings, int(flags) | _lib.GSR_FLAG_RAW_PARAMS, 1 + rest.shape[1], args,
+                             xyz.shape[0])
     if factored_sh_grad:
         flags |= _lib.GSR_FLAG_FACTORED_SH_GRAD
     return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
@@ -515,6 +586,16 @@ def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_ra
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                         cov3Ds_precomp, raster_settings, flags=None):
+    wide = colors_precomp is not None and colors_precomp.dim() == 2 and colors_precomp.shape[1] != 3
+    if not wide and not _wants_grad(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
+        device = means3D.device
+        args = [_f32c(t, n, device) for t, n in ((means3D, "means3D"), (sh, "shs"), (colors_precomp, "colors_precomp"),
+                                                 (opacities, "opacities"), (scales, "scales"), (rotations, "rotations"),
+                                                 (cov3Ds_precomp, "cov3D_precomp"))] + [None]
+        if args[2] is not None and (args[2].dim() != 2 or args[2].shape[0] != means3D.shape[0]):
+            raise _lib.GsrError("colors_precomp must be [N,C]")
+        return _forward_only(device, raster_settings, DEFAULT_FLAGS if flags is None else flags,
+                             sh.shape[1] if sh is not None else 0, args, means3D.shape[0])
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      rotations, cov3Ds_precomp, raster_settings,
                                      DEFAULT_FLAGS if flags is None else flags)

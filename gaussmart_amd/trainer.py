@@ -96,7 +96,7 @@ def training_step(gaussians, viewpoint_cam, gt_image, opt, pipe, background, ite
         render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=not on_device)
     total, parts = training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam, pipe)
     total.backward(gradient=_unit_gradient(total))   # cached: saves the ones_like() fill of every step
-    rec = take_color_grad(gaussians.get_xyz.device) if factored else None
+    rec = take_color_grad(gaussians._xyz) if factored else None
     if factored:
         gaussians.optimizer.park_sh_gradient(gaussians._features_dc, gaussians._features_rest, rec)
     if step_optimizer:

@@ -26,8 +26,85 @@ class ViewParallel:
         self.overlap_local = bool(overlap_local)
         self._side = None           # side stream of the SH update
         self._pending = None        # event: SH update of the previous step finished
+        # opt-in accounting of EXPOSED communication (bench.py --gpus N): event pairs around every point where the
+        # step's own stream waits for a collective; exposed_ms() adds them up.  Off by default (two events per wait).
+        self.probe = False
+        self._probe_events = []
         self._gathered = None       # factored step: all-gathered colour-gradient records (grow-only)
         self._xyz_snap = None       # factored pipelined step: the positions the backward saw
+
+    def _wait_on_main(self, work, dev):
+        """The current stream waits for collective `work`; with the probe on, how long it actually stalls there is
+        recorded (0 when the collective had already finished: fully hidden)."""
+        if not self.probe or not torch.cuda.is_available():
+            work.wait()
+            return
+        s = torch.cuda.current_stream(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        work.wait()
+        e1.record(s)
+        self._probe_events.append((e0, e1))
+
+    def exposed_ms(self, reset=True):
+        """Sum (ms) of the main-stream stalls on collectives since the last call; synchronises the events."""
+        total = 0.0
+        for e0, e1 in self._probe_events:
+            e1.synchronize()
+            total += e0.elapsed_time(e1)
+        n = len(self._probe_events)
+        if reset:
+            self._probe_events = []
+        return total, n
+
+    def replica_checksum(self):
+        """Order-independent 64-bit fingerprints of every parameter tensor (sum of the raw bit patterns), for the
+        replica-equality check of a view-parallel run: replicas must stay BIT-identical."""
+        with torch.no_grad():
+            self.finish()
+            return torch.stack([p.detach().contiguous().view(torch.int32).to(torch.int64).sum() for p in self.g.parameters()])
+
+    def replicas_identical(self):
+        """True when every rank holds bit-identical parameters (all ranks must call this)."""
+        if self.world_size == 1:
+            return True
+        mine = self.replica_checksum()
+        if dist.get_backend(self.pg) != "nccl":
+            mine = mine.cpu()
+        ref = mine.clone()
+        dist.broadcast(ref, src=0, group=self.pg)
+        same = torch.tensor([1 if torch.equal(ref, mine) else 0], dtype=torch.int64, device=mine.device)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN, group=self.pg)
+        return bool(int(same.item()))
+
+    @torch.no_grad()
+    def resync_from_rank0(self, optimizer=None):
+        """Overwrite every replica's parameters (and the Adam moments / step counts of `optimizer`) with rank 0's."""
+        if self.world_size == 1:
+            return
+        self.finish()
+        tensors = [p.data for p in self.g.parameters()]
+        if optimizer is not None:
+            for p in self.g.parameters():
+                st = optimizer.state.get(p, {})
+                tensors += [st[k] for k in ("exp_avg", "exp_avg_sq") if k in st]
+        host = dist.get_backend(self.pg) != "nccl"
+        for t in tensors:
+            if host and t.is_cuda:
+                c = t.cpu()
+                dist.broadcast(c, src=0, group=self.pg)
+                t.copy_(c)
+            else:
+                dist.broadcast(t, src=0, group=self.pg)
+        if optimizer is not None:
+            for p in self.g.parameters():
+                st = optimizer.state.get(p, {})
+                if "step" in st:
+                    c = st["step"].detach().clone().cpu().reshape(1).double()
+                    if not host:
+                        c = c.to(p.device)
+                    dist.broadcast(c, src=0, group=self.pg)
+                    st["step"].fill_(float(c.item()))
 
     @property
     def world_size(self):
@@ -133,10 +210,17 @@ class ViewParallel:
             return
         self.finish()
         use_avg = self.average and dist.get_backend(self.pg) == "nccl"
+        probe = self.probe and rec.head.is_cuda
+        if probe:       # blocking exchange: everything between these two events is exposed
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(rec.head.device))
         dist.all_reduce(rec.head, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, group=self.pg)
         if self.average and not use_avg:
             rec.head.mul_(1.0 / self.world_size)
         rec.gathered, _ = self._gather_records(rec, False)
+        if probe:
+            e1.record(torch.cuda.current_stream(rec.head.device))
+            self._probe_events.append((e0, e1))
         rec.n_views = self.world_size
         rec.grad_scale = 1.0 / self.world_size if self.average else 1.0
 
@@ -177,7 +261,7 @@ class ViewParallel:
         snapped = torch.cuda.Event()
         snapped.record(torch.cuda.current_stream(dev))
         if w_head is not None:
-            w_head.wait()                                 # current stream waits for the geometry collective only
+            self._wait_on_main(w_head, dev)               # current stream waits for the geometry collective only
         if self._side is None:
             self._side = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(self._side):
@@ -190,7 +274,7 @@ class ViewParallel:
         optimizer.step()                                  # features have no .grad: skipped
         rec.flat.record_stream(self._side)
         self._pending = ev
-        rasterizer.set_pending_param_event(dev, ev, self._side)
+        rasterizer.set_pending_param_event(dev, ev, self._side, model=self.g._xyz)
 
     def reduce_and_step(self, optimizer, rec=None):
         """all-reduce + optimiser step of one iteration.  `rec`: the factored SH gradient of this iteration's backward
@@ -242,7 +326,7 @@ class ViewParallel:
         w_head = dist.all_reduce(head, op=op, group=self.pg, async_op=True)
         w_t1 = dist.all_reduce(tail[:cut], op=op, group=self.pg, async_op=True) if cut > 0 else None
         w_t2 = dist.all_reduce(tail[cut:], op=op, group=self.pg, async_op=True)
-        w_head.wait()                                     # current stream waits for the first collective only
+        self._wait_on_main(w_head, dev)                   # current stream waits for the first collective only
         optimizer.step(only=[p for p in params if p is not rest_p])
         if self._side is None:
             self._side = torch.cuda.Stream(device=dev)
@@ -256,14 +340,14 @@ class ViewParallel:
             ev.record(self._side)
         flat.record_stream(self._side)                    # its memory may be reused only after the side stream is done
         self._pending = ev
-        rasterizer.set_pending_param_event(dev, ev, self._side)
+        rasterizer.set_pending_param_event(dev, ev, self._side, model=self.g._xyz)
 
     def finish(self):
         """Make the current stream wait for the outstanding SH update of a pipelined step, if any."""
         if self._pending is not None:
             from . import rasterizer
             dev = self.g.parameters()[0].device
-            rasterizer.wait_pending_params(dev)                      # un-park it (no-op if a forward consumed it)
+            rasterizer.wait_pending_params(dev, model=self.g._xyz)   # un-park it (no-op if a forward consumed it)
             torch.cuda.current_stream(dev).wait_event(self._pending)
             self._pending = None
 

@@ -64,6 +64,11 @@ enum {
                                        the activations of scene/gaussian_model.py:37-43 (sigmoid, exp,
                                        normalize) run inside the kernels and the gradients returned are
                                        w.r.t. the raw parameters */
+    GSR_FLAG_FORWARD_ONLY = 128,    /* gsr_forward for inference (render.py / view.py under torch.no_grad();
+                                       utils/mesh_utils.py:100-123): colour, allmap and radii are produced as usual, but
+                                       nothing is kept for a backward -- the IMAGE buffer is not requested (out->image =
+                                       NULL), the touch words of BINNING are not written and gsr_backward must not be
+                                       called with these buffers.  Honoured for 3-channel output; ignored for wide payloads */
     GSR_FLAG_FACTORED_SH_GRAD = 32  /* gsr_backward with `shs`: the SH gradient of one view is the outer product
                                        basis_k(dir) x g_c of the 16 basis values of the view direction and the
                                        clamp-masked colour gradient g = dL/drgb (utils/sh_utils.py:57-112 is linear in

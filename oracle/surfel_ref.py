@@ -256,9 +256,12 @@ def tile_ranges(keys_sorted: np.ndarray, n_tiles: int) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------- per-tile
-def _tile_eval(px, py, Tm, xy, nrm, opa, rgb, flags, margins=False):
+def _tile_eval(px, py, Tm, xy, nrm, opa, rgb, flags, margins=False, flip_tol=None):
     """All (Gaussian, pixel) pairs of one tile.  Tm [L,3,3], xy [L,2], nrm [L,3], opa [L],
-    rgb [L,C]; px, py [P].  Returns the per-pixel accumulators (differentiable)."""
+    rgb [L,C]; px, py [P].  Returns the per-pixel accumulators (differentiable).
+    `flip_tol`: also return "sensitive" [L] -- list entries that blend (or nearly blend) into a pixel where ANY
+    discrete decision of the walk (alpha >= 1/255, rho3d <= rho2d, T(1-alpha) < 1e-4, T > 0.5, depth >= near,
+    alpha clamp) has a relative margin below flip_tol, i.e. could be taken differently in fp32."""
     L = Tm.shape[0]
     dt = Tm.dtype
     P = px.shape[0]
@@ -271,6 +274,8 @@ def _tile_eval(px, py, Tm, xy, nrm, opa, rgb, flags, margins=False):
                    med_contrib=zi - 1, first=zi)
         if margins:
             out.update(m_alpha=inf, m_term=inf, m_med=inf, m_rho=inf)
+        if flip_tol is not None:
+            out["sensitive"] = torch.zeros(0, dtype=torch.bool)
         return out
     Tu, Tv, Tw = Tm[:, 0, :], Tm[:, 1, :], Tm[:, 2, :]
     pxb, pyb = px[None, :], py[None, :]
@@ -357,6 +362,23 @@ def _tile_eval(px, py, Tm, xy, nrm, opa, rgb, flags, margins=False):
         out["m_med"] = torch.where(contrib, (T_i.detach() - 0.5).abs(), big).amin(0)
         out["m_rho"] = torch.where(contrib, (rho3d.detach() - rho2d.detach()).abs()
                                    / (rho.detach() + 1e-12), big).amin(0)
+    if flip_tol is not None:
+        big = torch.full_like(alpha, float("inf")).detach()
+        live = ar <= first[None, :]
+        a_d, araw_d, dep_d = alpha.detach(), a_raw.detach(), depth.detach()
+        near_alpha = pre_alpha_valid & live
+        pair_m = torch.where(near_alpha, (a_d - ALPHA_MIN).abs() / ALPHA_MIN, big)
+        pair_m = torch.minimum(pair_m, torch.where(valid & live, (cum - T_EPS).abs() / T_EPS, big))
+        pair_m = torch.minimum(pair_m, torch.where(contrib, (T_i.detach() - 0.5).abs(), big))
+        pair_m = torch.minimum(pair_m, torch.where(contrib, (rho3d.detach() - rho2d.detach()).abs()
+                                                   / (rho.detach() + 1e-12), big))
+        pair_m = torch.minimum(pair_m, torch.where(contrib, (araw_d - ALPHA_MAX).abs() / ALPHA_MAX, big))
+        pair_m = torch.minimum(pair_m, torch.where(live & (p2.detach() != 0) & (a_d >= ALPHA_MIN * (1 - flip_tol)),
+                                                   (dep_d - NEAR_N).abs() / NEAR_N, big))
+        unstable_px = pair_m.amin(0) < flip_tol                                   # [P]
+        blends = near_alpha & (a_d >= ALPHA_MIN * (1 - flip_tol))                 # [L,P]
+        out["sensitive"] = (blends & unstable_px[None, :]).any(1)
+        out["unstable_px"] = unstable_px
     return out
 
 
@@ -419,6 +441,30 @@ def render_tiles(geom_T, geom_xy, geom_nrm, geom_opa, geom_rgb, point_list, rang
     return RenderOut(color, allmap, final_T, n_contrib, luse, marg)
 
 
+def flip_sensitive_gaussians(geom_T, geom_xy, geom_nrm, geom_opa, geom_rgb, point_list, ranges, S: Settings,
+                             flags=QUIRKS_UPSTREAM, tol=1e-4, tiles=None):
+    """Bool [N]: Gaussians that blend into at least one pixel whose walk holds a decision with margin < tol (see
+    _tile_eval).  A fp32 evaluation may take such a decision the other way, which changes the gradient of EVERY
+    Gaussian blended into that pixel by a finite amount; all other Gaussians see the same decisions in fp32 and fp64,
+    so their gradients differ by rounding only.  Also returns the number of unstable pixels."""
+    W, H = S.image_width, S.image_height
+    gx = (W + TILE - 1) // TILE
+    dt = geom_T.dtype
+    mask = torch.zeros(geom_T.shape[0], dtype=torch.bool)
+    n_px = 0
+    with torch.no_grad():
+        for t in (range(ranges.shape[0]) if tiles is None else tiles):
+            ids = point_list[int(ranges[t, 0]):int(ranges[t, 1])]
+            if ids.shape[0] == 0:
+                continue
+            yy, xx = _tile_pixels(t, gx, W, H, dt)
+            o = _tile_eval(xx.to(dt), yy.to(dt), geom_T[ids], geom_xy[ids], geom_nrm[ids], geom_opa[ids],
+                           geom_rgb[ids], flags, flip_tol=tol)
+            mask[ids[o["sensitive"]]] = True
+            n_px += int(o["unstable_px"].sum())
+    return mask, n_px
+
+
 def render_tiles_backward(geom_T, geom_xy, geom_nrm, geom_opa, geom_rgb, point_list, ranges, luse,
                           S: Settings, dL_dcolor, dL_dallmap, flags=QUIRKS_UPSTREAM, tiles=None):
     """Per-tile recompute + autograd.  Returns gradients w.r.t. the five geom arrays."""
@@ -447,10 +493,13 @@ def render_tiles_backward(geom_T, geom_xy, geom_nrm, geom_opa, geom_rgb, point_l
 
 
 # ----------------------------------------------------------------------------- operator
+LAST = {}     # intermediate results of the most recent rasterize() call (binning, list use, image state): test aid
+
+
 class _OracleRasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, opacities, shs, colors_precomp, scales, rotations,
-                cov3D_precomp, S, flags):
+                cov3D_precomp, S, flags, tiles=None):
         N = means3D.shape[0]
         inputs = dict(means3D=means3D, opacities=opacities, shs=shs, colors_precomp=colors_precomp,
                       scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
@@ -476,7 +525,11 @@ class _OracleRasterize(torch.autograd.Function):
         ranges = tile_ranges(keys, gx * gy)
         plist_t = torch.from_numpy(plist.astype(np.int64))
         full_geom = [full(geom.Tm), full(geom.xy), full(geom.normal), full(opa_v), full(rgb_v)]
-        out = render_tiles(*full_geom, plist_t, ranges, S, flags)
+        out = render_tiles(*full_geom, plist_t, ranges, S, flags, tiles=tiles)
+        ctx.tiles = tiles
+        LAST.clear()
+        LAST.update(full_geom=full_geom, point_list=plist_t, ranges=ranges, luse=out.luse, n_contrib=out.n_contrib,
+                    final_T=out.final_T, geom=geom)
         ctx.S, ctx.flags, ctx.geom, ctx.leaves = S, flags, geom, leaves
         ctx.stage1 = (geom.Tm, geom.xy, geom.normal, opa_v, rgb_v)
         ctx.full_geom, ctx.plist, ctx.ranges, ctx.luse = full_geom, plist_t, ranges, out.luse
@@ -489,7 +542,7 @@ class _OracleRasterize(torch.autograd.Function):
     def backward(ctx, dL_dcolor, _dradii, dL_dallmap):
         S, geom = ctx.S, ctx.geom
         gT, gxy, gn, go, gc = render_tiles_backward(*ctx.full_geom, ctx.plist, ctx.ranges, ctx.luse,
-                                                    S, dL_dcolor, dL_dallmap, ctx.flags)
+                                                    S, dL_dcolor, dL_dallmap, ctx.flags, tiles=ctx.tiles)
         N = gT.shape[0]
         vi = geom.vis_idx
         # [U] densification "hack": means2D.grad = (dL/dTu.z * Tw.z * W/2, dL/dTv.z * Tw.z * H/2, 0)
@@ -511,20 +564,21 @@ class _OracleRasterize(torch.autograd.Function):
         gmap = dict(zip([k for k in names if ctx.leaves[k] is not None], res))
         return (gmap.get("means3D"), g2d, gmap.get("opacities"), gmap.get("shs"),
                 gmap.get("colors_precomp"), gmap.get("scales"), gmap.get("rotations"),
-                gmap.get("cov3D_precomp"), None, None)
+                gmap.get("cov3D_precomp"), None, None, None)
 
 
 def rasterize(means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
-              rotations=None, cov3D_precomp=None, *, settings: Settings, flags=QUIRKS_UPSTREAM):
+              rotations=None, cov3D_precomp=None, *, settings: Settings, flags=QUIRKS_UPSTREAM, tiles=None):
     """Oracle with the operator signature of GaussianRasterizer.forward
-    (call site gaussian_renderer/__init__.py:97-106).  Returns (color, radii, allmap)."""
+    (call site gaussian_renderer/__init__.py:97-106).  Returns (color, radii, allmap).
+    `tiles` (test aid): composite, and backpropagate through, only these tiles; the images stay zero elsewhere."""
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
     if ((scales is None or rotations is None) and cov3D_precomp is None) or \
             ((scales is not None or rotations is not None) and cov3D_precomp is not None):
         raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
     return _OracleRasterize.apply(means3D, means2D, opacities, shs, colors_precomp, scales,
-                                  rotations, cov3D_precomp, settings, flags)
+                                  rotations, cov3D_precomp, settings, flags, tiles)
 
 
 class OracleRasterizer(torch.nn.Module):
