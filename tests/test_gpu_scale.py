@@ -23,10 +23,45 @@ def _run(dev, n, w, h, seed, radius_px):
     return m, pkg
 
 
-@pytest.mark.parametrize("name,n,w,h,radius_px", [("scan24-like", 300_000, 1600, 1200, 8.0),
-                                                  ("bicycle-like", 5_000_000, 1237, 822, 4.0)])
-def test_full_size_configs(gpu_device, name, n, w, h, radius_px):
+def _instances(dev, n, w, h, seed, radius_px):
+    """Instance count D and tile-list statistics of the frame _run() renders (forward-only debug call)."""
+    from conftest import hip_settings
+    from gaussmart_amd.rasterizer import rasterize_debug
+    from gaussmart_amd.synthetic import make_scene, jittered_cameras, activate
+    params, _ = make_scene(n, w, h, seed=seed, radius_px=radius_px)
+    cam = jittered_cameras(2, w, h, seed=seed, device=dev)[1]
+    a = {k: v.to(dev) for k, v in activate(params).items()}
+    dbg = rasterize_debug(a["means3D"], a["opacities"], a["shs"], None, a["scales"], a["rotations"], None,
+                          raster_settings=hip_settings(cam, 3, (0.0, 0.0, 0.0), dev))
+    D = dbg["num_rendered"]
+    vis = int((dbg["radii"] > 0).sum())
+    walked = dbg["n_contrib"][0].float()
+    return D, vis, float(walked.mean()), int(walked.max())
+
+
+# SURVEY 8(a) A4: scan24 D = 2-4 M at ~10 tiles per Gaussian; bicycle D = 20-40 M.  The radii are chosen to land there
+# (bench.py --preset scan24 / bicycle use the same values).
+@pytest.mark.parametrize("name,n,w,h,radius_px,d_range", [("scan24-like", 300_000, 1600, 1200, 17.0, (2.0e6, 4.5e6)),
+                                                          ("bicycle-like", 5_000_000, 1237, 822, 9.0, (20e6, 40e6))])
+def test_full_size_configs(gpu_device, name, n, w, h, radius_px, d_range):
+    import gc
+    from gaussmart_amd.rasterizer import release_workspace
+    gc.collect(); release_workspace(); torch.cuda.empty_cache()
+    D, vis, walked_mean, walked_max = _instances(gpu_device, n, w, h, 0, radius_px)
+    tiles = ((w + 15) // 16) * ((h + 15) // 16)
+    print(f"\n[{name}] D = {D / 1e6:.2f} M instances ({D / max(vis, 1):.1f} tiles per visible Gaussian), mean tile list "
+          f"{D / tiles:.0f} entries, entries walked per pixel: mean {walked_mean:.0f}, max {walked_max}")
+    assert d_range[0] <= D <= d_range[1], D
+    exact_rows = 16 * D * 80 > (8 << 30)      # above GSR_EXACT_ROWS_BYTES the backward sizes the row buffer exactly
+    assert exact_rows == (name == "bicycle-like")
+    gc.collect(); release_workspace(); torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(gpu_device)
     m, pkg = _run(gpu_device, n, w, h, 0, radius_px)
+    peak = torch.cuda.max_memory_allocated(gpu_device) / 2**30
+    print(f"[{name}] peak HBM allocated over forward + backward: {peak:.2f} GiB (worst-case gradient-row bound would be "
+          f"{16 * D * 80 / 2**30:.1f} GiB; exact-row path {'ON' if exact_rows else 'off'})")
+    # bicycle: the 16 D x 80 B bound (~30-50 GiB) is never allocated; rows follow the measured count (~2.6 D)
+    assert peak < (20.0 if name == "bicycle-like" else 8.0), peak
     am, col = pkg["allmap"].detach(), pkg["render"].detach()
     assert torch.isfinite(col).all() and torch.isfinite(am).all()
     assert float(am[1].min()) >= 0.0 and float(am[1].max()) <= 1.0 and float(am[1].mean()) > 0.3
