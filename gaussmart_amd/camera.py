@@ -60,13 +60,20 @@ class Camera(torch.nn.Module):
     """scene/cameras.py:17-59 with an explicit device."""
 
     def __init__(self, colmap_id, R, T, FoVx, FoVy, image, gt_alpha_mask=None, image_name="",
-                 uid=0, trans=np.zeros(3), scale=1.0, data_device="cuda", width=None, height=None):
+                 uid=0, trans=np.zeros(3), scale=1.0, data_device="cuda", width=None, height=None,
+                 keep_image_on_device=True):
         super().__init__()
         self.uid, self.colmap_id, self.image_name = uid, colmap_id, image_name
         self.R, self.T, self.FoVx, self.FoVy = R, T, FoVx, FoVy
         self.data_device = torch.device(data_device)
         if image is not None:
-            self.original_image = image.clamp(0.0, 1.0).to(self.data_device)    # scene/cameras.py:40: resident on the device
+            # DEVIATION from scene/cameras.py:40, which keeps the clamped image on the HOST ("move to device at dataloader
+            # to reduce VRAM requirement") and lets train.py:112 copy it up every iteration: with 288 GB of HBM the
+            # images stay resident by default (a 1600x1200 RGB frame is 23 MB, so ~40 frames per GB);
+            # keep_image_on_device=False restores the reference's behaviour (trainer.train() moves the frame per iteration)
+            self.original_image = image.clamp(0.0, 1.0)
+            if keep_image_on_device:
+                self.original_image = self.original_image.to(self.data_device)
             self.image_width, self.image_height = image.shape[2], image.shape[1]
         else:
             self.original_image = None

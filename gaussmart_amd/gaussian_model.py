@@ -56,7 +56,7 @@ class GaussianModel:
     def capture(self):
         return (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling,
                 self._rotation, self._opacity, self.max_radii2D, self.xyz_gradient_accum, self.denom,
-                self._segments, self.optimizer.state_dict(), self.spatial_lr_scale)
+                self._segments, self.optimizer.state_dict(), float(self.spatial_lr_scale))
 
     def restore(self, model_args, training_args):
         (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling,
@@ -159,9 +159,9 @@ class GaussianModel:
     def update_learning_rate(self, iteration):
         for group in self.optimizer.param_groups:
             if group["name"] == "xyz":
-                lr = self.xyz_scheduler_args(iteration)
-                group["lr"] = lr
-                return lr
+                lr = float(self.xyz_scheduler_args(iteration))   # a plain float: the schedule computes in NumPy, and a NumPy
+                group["lr"] = lr                                  # scalar in the optimiser state would make the checkpoint
+                return lr                                         # (capture()) unloadable with torch.load(weights_only=True)
 
     def parameters(self):
         return [self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation]

@@ -272,6 +272,21 @@ def readColmapCameras(cam_extrinsics, cam_intrinsics, images_folder, open_images
     return infos
 
 
+def _create_once(ply_path, make):
+    """The converted point cloud is written by ONE process: under torchrun every rank loads the scene, and concurrent
+    writers / readers of the same file race.  Rank 0 writes (to a temporary name, then renames), the others wait at a
+    barrier before reading."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not multi or dist.get_rank() == 0:
+        if not os.path.exists(ply_path):
+            tmp = ply_path + f".tmp{os.getpid()}"
+            make(tmp)
+            os.replace(tmp, ply_path)
+    if multi:
+        dist.barrier()
+
+
 def readColmapSceneInfo(path, images=None, eval=False, llffhold=8, open_images=True):
     sparse = os.path.join(path, "sparse/0")
     if os.path.exists(os.path.join(sparse, "images.bin")):
@@ -285,12 +300,13 @@ def readColmapSceneInfo(path, images=None, eval=False, llffhold=8, open_images=T
     else:
         train, test = cams, []
     ply_path = os.path.join(sparse, "points3D.ply")
-    if not os.path.exists(ply_path):
+    def make(dst):
         try:
             xyz, rgb, _ = read_points3D_binary(os.path.join(sparse, "points3D.bin"))
         except FileNotFoundError:
             xyz, rgb, _ = read_points3D_text(os.path.join(sparse, "points3D.txt"))
-        storePly(ply_path, xyz, rgb, np.zeros(len(xyz), dtype=np.int32))
+        storePly(dst, xyz, rgb, np.zeros(len(xyz), dtype=np.int32))
+    _create_once(ply_path, make)
     return SceneInfo(fetchPly(ply_path), train, test, getNerfppNorm(train), ply_path)
 
 
@@ -324,10 +340,11 @@ def readNerfSyntheticInfo(path, white_background=False, eval=False, extension=".
     if not eval:
         train, test = train + test, []
     ply_path = os.path.join(path, "points3d.ply")
-    if not os.path.exists(ply_path):
+    def make(dst):
         rng = np.random.default_rng(seed)                # random points inside the Blender scene bounds
         xyz = rng.random((100_000, 3)) * 2.6 - 1.3
-        storePly(ply_path, xyz, SH2RGB(rng.random((100_000, 3)) / 255.0) * 255)
+        storePly(dst, xyz, SH2RGB(rng.random((100_000, 3)) / 255.0) * 255)
+    _create_once(ply_path, make)
     return SceneInfo(fetchPly(ply_path), train, test, getNerfppNorm(train), ply_path)
 
 

@@ -17,7 +17,7 @@ from .gaussian_renderer import render
 from .losses import psnr
 from .params import OptimizationParams, PipelineParams
 from .scene_io import Scene
-from .trainer import train
+from .trainer import train, TrainState
 from .view_parallel import ViewParallel
 
 
@@ -65,7 +65,9 @@ def main(argv=None):
     gaussians.training_setup(opt)
     first_iter = 0
     if args.start_checkpoint:
-        model_params, first_iter = torch.load(args.start_checkpoint, map_location=dev, weights_only=False)
+        # capture() holds ints, floats, tensors / Parameters and the optimiser's state_dict: the weights-only loader
+        # (no arbitrary pickle code from the file) is sufficient
+        model_params, first_iter = torch.load(args.start_checkpoint, map_location=dev, weights_only=True)
         gaussians.restore(model_params, opt)
     background = torch.tensor([1.0, 1.0, 1.0] if args.white_background else [0.0, 0.0, 0.0], device=dev)
     vp = ViewParallel(gaussians) if world > 1 else None
@@ -73,11 +75,14 @@ def main(argv=None):
     os.makedirs(args.model_path, exist_ok=True)
     t0 = time.time()
     done = first_iter
+    state = TrainState(seed=0)      # one view sampler for the whole run: saving does not perturb the trajectory
     for stop in sorted(set([i for i in args.save_iterations if first_iter < i <= args.iterations] + [args.iterations])):
         train(gaussians, scene.getTrainCameras(), opt, pipe, background, cameras_extent=scene.cameras_extent,
               first_iter=done, iterations=stop, view_parallel=vp, white_background=args.white_background,
-              log_every=args.log_every if rank == 0 else 0)
+              log_every=args.log_every if rank == 0 else 0, final_iteration=args.iterations, state=state)
         done = stop
+        if vp is not None:
+            vp.finish()
         if rank == 0:
             scene.save(stop)
             torch.save((gaussians.capture(), stop), os.path.join(args.model_path, f"chkpnt{stop}.pth"))

@@ -132,30 +132,54 @@ def densification_step(gaussians, render_pkg, opt, iteration, cameras_extent, wh
             gaussians.reset_opacity()
 
 
+class TrainState:
+    """What a training run carries from one iteration to the next besides the model: the view sampler (RNG, the
+    current epoch's stack of unvisited views, the epoch count).  Pass the same object to consecutive train() calls
+    (train_cli.py saves between them) and the trajectory is the one of a single uninterrupted call."""
+
+    def __init__(self, seed=0):
+        self.seed = seed
+        self.rng = random.Random(seed)
+        self.stack, self.epoch = None, 0
+
+
 def train(gaussians, cameras, opt, pipe, background, *, cameras_extent=1.0, first_iter=0, iterations=None,
-          view_parallel: ViewParallel = None, white_background=False, seed=0, log_every=0, log_fn=print):
+          view_parallel: ViewParallel = None, white_background=False, seed=0, log_every=0, log_fn=print,
+          final_iteration=None, state: TrainState = None, on_iteration=None):
     """cameras: objects with .original_image [3,H,W].  Epochs are shuffled stacks popped at random,
-    as train.py:99-102; under view parallelism each rank pops from its shard of the same shuffle."""
+    as train.py:99-102; under view parallelism each rank pops from its shard of the same shuffle.
+
+    Runs iterations first_iter+1 .. iterations.  As in the reference (train.py:214-216: `if iteration < opt.iterations`)
+    only the LAST iteration of the whole schedule skips the optimiser step: `final_iteration` (default: opt.iterations
+    when this call ends there, else none) names it, so a run split into several calls -- one per save point -- steps on
+    every intermediate stop exactly like an uninterrupted one.  `state` keeps the view sampler across such calls;
+    `on_iteration(iteration)` is called after each iteration's optimiser step (saving / evaluation hooks)."""
     iterations = opt.iterations if iterations is None else iterations
-    rng = random.Random(seed)
-    stack, epoch = None, 0
+    if final_iteration is None:
+        final_iteration = opt.iterations
+    st = state if state is not None else TrainState(seed)
+    rng = st.rng
     device = gaussians.get_xyz.device
     t0 = time.time()
     last = None
     for iteration in range(first_iter + 1, iterations + 1):
         if iteration % 1000 == 0:
             gaussians.oneupSHdegree()
-        if not stack:
-            stack = list(view_parallel.shard_views(cameras, seed + epoch)) if view_parallel else list(cameras)
-            epoch += 1
-        cam = stack.pop(rng.randint(0, len(stack) - 1))
+        if not st.stack:
+            st.stack = list(view_parallel.shard_views(cameras, st.seed + st.epoch)) if view_parallel else list(cameras)
+            st.epoch += 1
+        cam = st.stack.pop(rng.randint(0, len(st.stack) - 1))
         gt = cam.original_image.to(device)
         # the optimizer step comes after the densification bookkeeping, as in the reference
         render_pkg, last = training_step(gaussians, cam, gt, opt, pipe, background, iteration,
                                          view_parallel=view_parallel, step_optimizer=False)
         densification_step(gaussians, render_pkg, opt, iteration, cameras_extent, white_background, view_parallel)
-        if iteration < iterations:
+        if iteration < final_iteration:
             optimizer_step(gaussians)      # the exchange of a view-parallel run already happened in training_step
+        else:
+            gaussians.optimizer.zero_grad(set_to_none=True)   # the schedule's last iteration: no step (train.py:214)
+        if on_iteration is not None:
+            on_iteration(iteration)
         if log_every and iteration % log_every == 0:
             log_fn(f"[it {iteration}] loss {float(last['loss']):.5f} points {gaussians.get_xyz.shape[0]} "
                    f"{(iteration - first_iter) / (time.time() - t0):.2f} it/s")

@@ -129,3 +129,38 @@ def test_create_from_pcd_uses_knn_for_scales():
     torch.testing.assert_close(m._scaling[:, 0], torch.log(torch.sqrt(ref)))
     assert m._scaling.shape == (64, 2) and m._features_rest.shape == (64, 15, 3) and m._features_dc.shape == (64, 1, 3)
     torch.testing.assert_close(m.get_opacity, torch.full((64, 1), 0.1))
+
+
+def test_train_in_chunks_equals_one_uninterrupted_run(oracle_backend, tmp_path):
+    """train_cli.py calls train() once per save point.  With one TrainState and `final_iteration` = the end of the
+    schedule the split run must be the uninterrupted one bit for bit: every intermediate stop steps the optimiser
+    (reference train.py:214-216 skips the step only on the schedule's last iteration) and the view sampler carries on.
+    The checkpoint written at a stop reloads with the weights-only loader."""
+    from gaussmart_amd.camera import Camera
+    from gaussmart_amd.synthetic import jittered_cameras
+    from gaussmart_amd.trainer import train, TrainState
+    pipe, bg = PipelineParams(), torch.zeros(3)
+    opt = OptimizationParams(iterations=8012)
+    cams = jittered_cameras(3, 48, 48, seed=4, device="cpu")
+    for i, c in enumerate(cams):
+        c.original_image = torch.rand(3, 48, 48, generator=torch.Generator().manual_seed(i))
+
+    def fresh():
+        params, _ = make_scene(120, 48, 48, seed=6, device="cpu")
+        m = GaussianModel(3, device="cpu"); m.use_fused_adam = False
+        m.create_from_params(params); m.training_setup(opt)
+        return m
+
+    one = fresh()
+    train(one, cams, opt, pipe, bg, first_iter=8000, iterations=8012)
+    split = fresh()
+    st = TrainState(seed=0)
+    train(split, cams, opt, pipe, bg, first_iter=8000, iterations=8005, final_iteration=8012, state=st)
+    torch.save((split.capture(), 8005), tmp_path / "chk.pth")
+    snap, it = torch.load(tmp_path / "chk.pth", weights_only=True)
+    assert it == 8005 and torch.equal(snap[1], split.get_xyz)
+    train(split, cams, opt, pipe, bg, first_iter=8005, iterations=8012, final_iteration=8012, state=st)
+    for a, b in zip(one.parameters(), split.parameters()):
+        assert torch.equal(a, b)
+    # the last iteration of the schedule leaves no stale gradient behind
+    assert all(p.grad is None for p in split.parameters())
