@@ -288,7 +288,12 @@ def main():
     model.training_setup(opt)
     force_dp = bool(os.environ.get("GSR_BENCH_FORCE_DP")) and dist.is_initialized()   # rehearsal on one GPU
     vp = ViewParallel(model, force=force_dp) if (world > 1 or force_dp) else None
-    if vp is None and os.environ.get("GSR_BENCH_LOCAL_OVERLAP"):     # A/B aid: SH update on a side stream at N = 1
+    if vp is None and os.environ.get("GSR_BENCH_LOCAL_OVERLAP", "1") != "0":
+        # N = 1: the same step pipeline as N > 1, minus the exchange -- the HBM-bound SH update (and the next forward's SH
+        # colour pass behind it) run on a side stream beside the next forward's latency-bound depth sort / binning.  Same
+        # kernels, same arithmetic, bit-identical parameters (tests/test_gpu_view_parallel.py); everything is joined by
+        # the synchronisation that ends the timed region.  GSR_BENCH_LOCAL_OVERLAP=0: strictly serial step
+        # (same box, 200 steps, three alternating runs each: 470.4 / 474.9 / 477.3 vs 482.9 / 483.2 / 478.8 it/s).
         vp = ViewParallel(model, overlap_local=True)
 
     base_iter = 10_000
@@ -442,7 +447,9 @@ def main():
                        "preset": args.preset, "gaussians": N, "width": W, "height": H, "radius_px": radius_px, "instances_D": D,
                        "tile_list_mean": round(D / tiles, 1), "entries_walked_per_pixel_mean": round(float(nc.mean()), 1),
                        "entries_walked_per_pixel_max": int(nc.max()),
-                       "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU"},
+                       "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",
+                       "step_pipeline": "SH Adam update + next colour pass on a side stream beside the next forward's binning"
+                                        if (vp is not None and (vp.overlap_local or world > 1 or force_dp)) else "serial"},
             "ms_per_step_median": median_ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw,

@@ -14,7 +14,8 @@ import threading
 import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgsr_hip.so")
+# GSR_LIB_PATH: developer aid for same-box A/B runs of two builds of the library (scripts/ab_builds.sh)
+LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(_HERE, "lib", "libgsr_hip.so")
 ABI_VERSION = 3
 
 GSR_BUF_GEOM, GSR_BUF_BINNING, GSR_BUF_IMAGE, GSR_BUF_SCRATCH, GSR_BUF_SCRATCH2 = range(5)

@@ -58,6 +58,19 @@ struct RenderBwdParams {
     const float* feat; const uint32_t* point_list; float* feat_rows; int C;
 };
 
+// lowest set bit of a 64-bit scalar mask (-1 if empty: s_ff1 says so itself) and its removal -- one scalar
+// instruction each (s_bitset0 with index -1 clears bit 63 of a mask that is empty anyway)
+__device__ __forceinline__ int rb_take_first(unsigned long long& m) {
+    int j;
+    asm("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(j), "+s"(m));
+    return j;
+}
+__device__ __forceinline__ uint32_t rb_pack16(int lo, int hi) {
+    uint32_t r;
+    asm("s_pack_ll_b32_b16 %0, %1, %2" : "=s"(r) : "s"(lo), "s"(hi));
+    return r;
+}
+
 #ifndef RB_MIN_WAVES
 #define RB_MIN_WAVES 4   // <= 128 VGPRs, no scratch: measured 0.825 ms at 1M/1080p (5 waves spill: 1.13 ms)
 #endif
@@ -83,6 +96,7 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
     const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
     const int grp = lane >> 4, l16 = lane & 15;   // DPP row = 4x4 pixel block, same mapping as render_fwd
     const uint32_t below_mask = ((1u << (8 * wave + grp)) - 1u) & 0x0F0F0F0Fu;   // touch bits of the blocks before mine
+    const uint32_t pick_shift = (uint32_t)grp * 16u;   // where this row's pick sits in the packed 64-bit scalar
     const int pxi = qx0 + (grp & 1) * 4 + (l16 & 3), pyi = qy0 + (grp >> 1) * 4 + (l16 >> 2);
     const bool inside = pxi < p.W && pyi < p.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
@@ -202,21 +216,23 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
         // only the splats the forward blended into >= 1 pixel of a block carry any gradient there: one to-do
         // mask per 4x4 block (= DPP row), held by all 16 lanes of the row
         // (the four masks live in SGPRs: picking and clearing bits is scalar work, the vector unit only selects)
+        // (the masks are kept BIT-REVERSED: the deepest entry of a block is then the lowest set bit, which s_ff1 finds
+        // and reports as -1 on an empty mask by itself -- two scalar instructions per block and iteration)
         unsigned long long m0, m1, m2, m3;
         {
             const uint32_t t = lane < nb ? (touch_of_lane >> (8 * wave)) & 0xFu : 0u;
-            m0 = __ballot((t & 1u) != 0); m1 = __ballot((t & 2u) != 0);
-            m2 = __ballot((t & 4u) != 0); m3 = __ballot((t & 8u) != 0);
+            m0 = __builtin_bitreverse64(__ballot((t & 1u) != 0)); m1 = __builtin_bitreverse64(__ballot((t & 2u) != 0));
+            m2 = __builtin_bitreverse64(__ballot((t & 4u) != 0)); m3 = __builtin_bitreverse64(__ballot((t & 8u) != 0));
         }
-        while ((m0 | m1 | m2 | m3) != 0ull) {
-            // deepest entry of each block's mask first
-            const int j0 = m0 ? 63 - __builtin_clzll(m0) : -1, j1 = m1 ? 63 - __builtin_clzll(m1) : -1;
-            const int j2 = m2 ? 63 - __builtin_clzll(m2) : -1, j3 = m3 ? 63 - __builtin_clzll(m3) : -1;
-            m0 &= ~(1ull << (j0 & 63)); m1 &= ~(1ull << (j1 & 63));      // (an empty mask stays empty)
-            m2 &= ~(1ull << (j2 & 63)); m3 &= ~(1ull << (j3 & 63));
-            const int jr = grp == 0 ? j0 : grp == 1 ? j1 : grp == 2 ? j2 : j3;
-            const bool has = jr >= 0;
-            const int j = max(jr, 0);
+        for (;;) {
+            // deepest entry of each block's mask first; the four picks reach the lanes packed in one 64-bit scalar
+            const int r0_ = rb_take_first(m0), r1_ = rb_take_first(m1), r2_ = rb_take_first(m2), r3_ = rb_take_first(m3);
+            const uint32_t p01 = rb_pack16(r0_, r1_), p23 = rb_pack16(r2_, r3_);
+            if ((p01 & p23) == 0xFFFFFFFFu) break;                  // all four masks were empty
+            const unsigned long long picks = ((unsigned long long)p23 << 32) | p01;
+            const int jrev = (int)(short)(picks >> pick_shift);     // this row's pick in reversed numbering; -1: none
+            const bool has = jrev >= 0;
+            const int j = (63 - jrev) & 63;
             const int cidx = lo + j;                            // 0-based position in the tile list
             const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
             const float4 a3 = s_rec[j * 5 + 3];

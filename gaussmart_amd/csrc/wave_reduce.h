@@ -23,9 +23,31 @@ __device__ __forceinline__ float dpp_move(float v) {
 __device__ __forceinline__ float row_sum16_transposed(const float (&v)[16], int l16) {
     const bool b1 = (l16 & 2) != 0, b0 = (l16 & 1) != 0;
     float r[8], q[4], p[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)        // bit 3: partner is lane ^ 8 (row_ror:8); lanes 0..7 = banks 0,1 keep v[i]
-        GSR_DPP_PAIR(r[i], v[i], v[i + 8], "row_ror:8", "0x3", "0xc", "s_nop 1\n\t");
+    // bit 3: partner is lane ^ 8 (row_ror:8); lanes 0..7 = banks 0,1 keep v[i].  ONE asm statement for the eight pairs,
+    // so the "VALU write -> DPP read" hazard (2 wait states, invisible to the hazard recogniser across an asm boundary)
+    // is paid with one s_nop instead of eight.
+#define GSR_P8(i) "v_add_f32_dpp %" #i ", %" #i "+8, %" #i "+8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %0, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %1, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %2, %18, %18 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %3, %19, %19 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %4, %20, %20 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %5, %21, %21 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %6, %22, %22 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %7, %23, %23 row_ror:8 row_mask:0xf bank_mask:0xc"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+                   "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+#undef GSR_P8
 #pragma unroll
     for (int i = 0; i < 4; ++i)        // bit 2: partner is lane ^ 7 (row_half_mirror); banks 0,2 keep r[i]
         GSR_DPP_PAIR(q[i], r[i], r[i + 4], "row_half_mirror", "0x5", "0xa", "");   // inputs written >= 6 instructions ago
