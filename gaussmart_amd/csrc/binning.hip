@@ -175,14 +175,18 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_digit_scan_kernel(uint32_t* __res
     if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
 }
 
-template <int BITS>
+// V2: a SECOND value array travels with the pairs (the tile sort carries the Gaussian id next to the emission index, so
+// that no pass has to gather one through the other afterwards: at D = 20 M that gather cost 0.4 ms per frame).
+template <int BITS, bool V2>
 __global__ void __launch_bounds__(RS_BLOCK) rs_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                               const uint32_t* __restrict__ vals_in,
                                                               uint32_t* __restrict__ keys_out,
                                                               uint32_t* __restrict__ vals_out, int64_t n,
                                                               int shift, int nblocks,
                                                               const uint32_t* __restrict__ table_scanned,
-                                                              const uint32_t* __restrict__ digit_total) {
+                                                              const uint32_t* __restrict__ digit_total,
+                                                              const uint32_t* __restrict__ vals2_in,
+                                                              uint32_t* __restrict__ vals2_out) {
     constexpr int NB = 1 << BITS;
     constexpr uint32_t MASK = NB - 1;
     __shared__ uint32_t wave_hist[RS_WAVES][NB];
@@ -190,6 +194,7 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_scatter_kernel(const uint32_t* __
     __shared__ uint32_t gbase[NB];         // global base of (digit, this block)
     __shared__ uint32_t s_keys[RS_TILE];
     __shared__ uint32_t s_vals[RS_TILE];
+    __shared__ uint32_t s_vals2[V2 ? RS_TILE : 1];
     __shared__ uint32_t wt[RS_WAVES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -206,7 +211,7 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_scatter_kernel(const uint32_t* __
     const int block_n = (int)min((int64_t)RS_TILE, n - block_base);
     const int wave_base_idx = wave * (RS_TILE / RS_WAVES);
 
-    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], val2[V2 ? RS_ITEMS : 1], rank[RS_ITEMS];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
@@ -215,6 +220,7 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_scatter_kernel(const uint32_t* __
         key[r] = valid ? keys_in[block_base + local] : 0xFFFFFFFFu;
         // vals_in == NULL means "values are the element indices" (first pass of an argsort)
         val[r] = valid ? (vals_in ? vals_in[block_base + local] : (uint32_t)(block_base + local)) : 0u;
+        if (V2) val2[r] = valid ? vals2_in[block_base + local] : 0u;
         const uint32_t d = (key[r] >> shift) & MASK;
         // lanes holding the same digit (among valid lanes)
         unsigned long long same = __ballot(valid);
@@ -263,6 +269,7 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_scatter_kernel(const uint32_t* __
             const uint32_t pos = digit_start[d] + wave_hist[wave][d] + rank[r];
             s_keys[pos] = key[r];
             s_vals[pos] = val[r];
+            if (V2) s_vals2[pos] = val2[r];
         }
     }
     __syncthreads();
@@ -275,6 +282,7 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_scatter_kernel(const uint32_t* __
             const size_t g = (size_t)gbase[d] + (uint32_t)(pos - digit_start[d]);
             keys_out[g] = k;
             vals_out[g] = s_vals[pos];
+            if (V2) vals2_out[g] = s_vals2[pos];
         }
     }
 }
@@ -297,11 +305,14 @@ size_t gsr_sort_ws_bytes(int64_t n) {
 
 int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
                          uint32_t* vals_out, uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n,
-                         int begin_bit, int end_bit, void* ws, hipStream_t s) {
+                         int begin_bit, int end_bit, void* ws, hipStream_t s,
+                         const uint32_t* vals2_in, uint32_t* vals2_out, uint32_t* vals2_tmp) {
     if (n <= 0) return GSR_OK;
     const int bits = end_bit - begin_bit;
+    const bool v2 = vals2_in != nullptr;
     if (bits <= 0) {   // nothing to sort on: stable sort is the identity
         GSR_HIP_CHECK(hipMemcpyAsync(keys_out, keys_in, size_t(n) * 4, hipMemcpyDeviceToDevice, s));
+        if (v2) GSR_HIP_CHECK(hipMemcpyAsync(vals2_out, vals2_in, size_t(n) * 4, hipMemcpyDeviceToDevice, s));
         if (vals_in) GSR_HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, size_t(n) * 4, hipMemcpyDeviceToDevice, s));
         else hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, vals_out, n);
         GSR_LAUNCH_CHECK();
@@ -314,7 +325,7 @@ int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint3
     uint32_t* digit_total = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + gsr_align(e * 4));
 
     // ping-pong so that the last pass lands in *_out
-    const uint32_t* src_k = keys_in; const uint32_t* src_v = vals_in;
+    const uint32_t* src_k = keys_in; const uint32_t* src_v = vals_in; const uint32_t* src_v2 = vals2_in;
     int bit = begin_bit;
     for (int p = 0; p < passes; ++p) {
         const int remaining_passes = passes - p;
@@ -324,6 +335,7 @@ int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint3
         const bool to_out = ((passes - 1 - p) % 2) == 0;
         uint32_t* dst_k = to_out ? keys_out : keys_tmp;
         uint32_t* dst_v = to_out ? vals_out : vals_tmp;
+        uint32_t* dst_v2 = to_out ? vals2_out : vals2_tmp;
         {
             GsrProfileScope prof(GSR_K_SORT_HIST, s);
             hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_BLOCK), 0, s, src_k, n, bit,
@@ -335,14 +347,16 @@ int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint3
         }
         {
             GsrProfileScope prof(GSR_K_SORT_SCATTER, s);
-#define RS_CASE(B) case B: hipLaunchKernelGGL(rs_scatter_kernel<B>, dim3(nblocks), dim3(RS_BLOCK), 0, s, \
-                                              src_k, src_v, dst_k, dst_v, n, bit, nblocks, table, digit_total); break;
+#define RS_CASE(B) case B: if (v2) hipLaunchKernelGGL((rs_scatter_kernel<B, true>), dim3(nblocks), dim3(RS_BLOCK), 0, s, \
+                                              src_k, src_v, dst_k, dst_v, n, bit, nblocks, table, digit_total, src_v2, dst_v2); \
+                   else hipLaunchKernelGGL((rs_scatter_kernel<B, false>), dim3(nblocks), dim3(RS_BLOCK), 0, s, \
+                                              src_k, src_v, dst_k, dst_v, n, bit, nblocks, table, digit_total, nullptr, nullptr); break;
             switch (w) { RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
                 default: gsr_set_error("radix digit width %d", w); return GSR_E_INVALID; }
 #undef RS_CASE
         }
         GSR_LAUNCH_CHECK();
-        src_k = dst_k; src_v = dst_v;
+        src_k = dst_k; src_v = dst_v; src_v2 = dst_v2;
         bit += w;
     }
     return GSR_OK;
@@ -424,48 +438,24 @@ int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const 
     return GSR_OK;
 }
 
-// Per sorted instance: Gaussian id and the tile ranges (the emission index is the sort's own value output).  (The 80-byte records themselves are
-// NOT copied into list order any more: the render kernels gather them by id, see render_fwd.hip.)
+// Tile ranges from the sorted tile keys (Gaussian id and emission index of every list entry are the tile sort's own two
+// value outputs; the 80-byte records themselves are NOT copied into list order: the render kernels gather them by id).
 __global__ void __launch_bounds__(256) finalize_bins_kernel(int D, const uint32_t* __restrict__ tile_sorted,
-                                                            const uint32_t* __restrict__ inst_row,
-                                                            const uint32_t* __restrict__ emit_gid,
-                                                            uint32_t* __restrict__ point_list,
                                                             uint32_t* __restrict__ ranges) {
-    // four entries per thread, one block-stride apart: the four dependent gathers (entry -> emission index ->
-    // Gaussian id) are in flight together instead of one per thread
-    const int i0 = blockIdx.x * (blockDim.x * 4) + threadIdx.x;
-    uint32_t e[4], t[4], tp[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * 256;
-        e[u] = 0; t[u] = 0; tp[u] = 0;
-        if (i < D) {
-            e[u] = inst_row[i];   // inst_row = the tile sort's value output (emission index per entry)
-            t[u] = tile_sorted[i];
-            tp[u] = i > 0 ? tile_sorted[i - 1] : 0xFFFFFFFFu;
-        }
-    }
-    uint32_t g[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) g[u] = i0 + u * 256 < D ? emit_gid[e[u]] : 0u;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * 256;
-        if (i >= D) continue;
-        point_list[i] = g[u];
-        if (i == 0) ranges[2 * t[u]] = 0;
-        else if (tp[u] != t[u]) { ranges[2 * tp[u] + 1] = i; ranges[2 * t[u]] = i; }
-        if (i == D - 1) ranges[2 * t[u] + 1] = D;
-    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    const uint32_t t = tile_sorted[i];
+    const uint32_t tp = i > 0 ? tile_sorted[i - 1] : 0xFFFFFFFFu;
+    if (i == 0) ranges[2 * t] = 0;
+    else if (tp != t) { ranges[2 * tp + 1] = i; ranges[2 * t] = i; }
+    if (i == D - 1) ranges[2 * t + 1] = D;
 }
 
-int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted, const uint32_t* inst_row,
-                             const uint32_t* emit_gid, uint32_t* point_list, uint32_t* ranges, hipStream_t s) {
+int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted, uint32_t* ranges, hipStream_t s) {
     GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
     if (D <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_FINALIZE, s);
-    hipLaunchKernelGGL(finalize_bins_kernel, dim3((unsigned)((D + 1023) / 1024)), dim3(256), 0, s, D,
-                       tile_keys_sorted, inst_row, emit_gid, point_list, ranges);
+    hipLaunchKernelGGL(finalize_bins_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, D, tile_keys_sorted, ranges);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

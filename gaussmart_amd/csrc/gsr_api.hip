@@ -286,7 +286,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     if (D > 0) {
         const size_t db = gsr_align(size_t(D) * 4);
         const size_t sort_ws_d = gsr_sort_ws_bytes(D);
-        char* sc2 = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH2, 7 * db + sort_ws_d));
+        char* sc2 = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH2, 8 * db + sort_ws_d));
         if (!sc2) { gsr_set_error("allocator returned NULL (scratch2)"); return GSR_E_ALLOC; }
         uint32_t* tile_keys = reinterpret_cast<uint32_t*>(sc2);
         uint32_t* emit_gid = reinterpret_cast<uint32_t*>(sc2 + 2 * db);
@@ -294,14 +294,16 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         uint32_t* perm = inst_row;   // the sorted values ARE the emission indices of the list entries: sort straight into place
         uint32_t* tk_tmp = reinterpret_cast<uint32_t*>(sc2 + 5 * db);
         uint32_t* tv_tmp = reinterpret_cast<uint32_t*>(sc2 + 6 * db);
-        void* sort_ws2 = sc2 + 7 * db;
+        uint32_t* tg_tmp = reinterpret_cast<uint32_t*>(sc2 + 7 * db);
+        void* sort_ws2 = sc2 + 8 * db;
         rc = gsr_launch_emit(N, gx, gy, order, offs, rank_rect, tile_keys, emit_gid, s);
         if (rc != GSR_OK) return rc;
-        // values = emission indices 0..D-1: the sort generates them itself (vals_in = NULL)
+        // values = emission indices 0..D-1: the sort generates them itself (vals_in = NULL); the Gaussian ids travel as a
+        // second value array straight into point_list (no gather through the emission index afterwards)
         rc = gsr_radix_sort_pairs(tile_keys, nullptr, tile_sorted, perm, tk_tmp, tv_tmp, D, 0,
-                                  bits_for((uint32_t)n_tiles), sort_ws2, s);
+                                  bits_for((uint32_t)n_tiles), sort_ws2, s, emit_gid, point_list, tg_tmp);
         if (rc != GSR_OK) return rc;
-        rc = gsr_launch_finalize_bins((int)D, n_tiles, tile_sorted, inst_row, emit_gid, point_list, ranges, s);
+        rc = gsr_launch_finalize_bins((int)D, n_tiles, tile_sorted, ranges, s);
         if (rc != GSR_OK) return rc;
     } else {
         GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
@@ -317,7 +319,8 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     }
     return gsr_launch_render_fwd(*view, ranges, splat, fwd_only ? nullptr : at<float>(image, IL.final_T),
                                  fwd_only ? nullptr : at<uint32_t>(image, IL.n_contrib), out->out_color, out->out_allmap,
-                                 at<uint8_t>(binning, BL.touch), view->channels == 3 ? nullptr : g->colors_precomp,
+                                 at<uint8_t>(binning, BL.touch), at<uint32_t>(binning, BL.covered),
+                                 view->channels == 3 ? nullptr : g->colors_precomp,
                                  point_list, s);
 }
 
@@ -376,7 +379,9 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     size_t n_rows = n_inst * GSR_SUBROWS;       // the bound
     const uint32_t* touch = at<uint32_t>(binning, BL.touch);
     if (num_rendered > 0) {
-        rc = gsr_launch_slot_count(num_rendered, touch, at<uint32_t>(binning, BL.inst_row), slot_cnt, s);
+        GSR_HIP_CHECK(hipMemsetAsync(slot_cnt, 0, size_t(num_rendered), s));   // instances nobody walked keep 0 rows
+        rc = gsr_launch_slot_count(num_rendered, gx * gy, at<uint32_t>(binning, BL.ranges), at<uint32_t>(binning, BL.covered),
+                                   touch, at<uint32_t>(binning, BL.inst_row), slot_cnt, s);
         if (rc != GSR_OK) return rc;
         rc = gsr_exclusive_scan_u8(slot_cnt, slot_off, num_rendered, scan_ws, s);
         if (rc != GSR_OK) return rc;
@@ -398,7 +403,8 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     float* feat_rows = wide ? reinterpret_cast<float*>(rows_mem + rows_bytes) : nullptr;
 
     if (num_rendered > 0) {
-        rc = gsr_launch_render_bwd(*view, at<uint32_t>(binning, BL.ranges), at<uint32_t>(binning, BL.inst_row),
+        rc = gsr_launch_render_bwd(*view, at<uint32_t>(binning, BL.ranges), at<uint32_t>(binning, BL.covered),
+                                   at<uint32_t>(binning, BL.inst_row),
                                    at<float>(geom, GL.splat), touch, slot_off, at<float>(image, IL.final_T),
                                    at<uint32_t>(image, IL.n_contrib), dL_dcolor, dL_dallmap, grad_rows,
                                    wide ? g->colors_precomp : nullptr, at<uint32_t>(binning, BL.point_list), feat_rows, s);

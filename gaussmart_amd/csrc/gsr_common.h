@@ -78,12 +78,16 @@ struct GsrGeomLayout {
     }
 };
 struct GsrBinLayout {
-    size_t point_list, inst_row, ranges, touch, total;
+    size_t point_list, inst_row, ranges, covered, touch, total;
     GsrBinLayout(int64_t D, int64_t tiles) {
         size_t o = 0;
         point_list = o; o += gsr_align(size_t(D) * 4);
         inst_row = o;   o += gsr_align(size_t(D) * 4);
         ranges = o;     o += gsr_align(size_t(tiles) * 8);
+        // per (tile, quad): how many entries of the tile's list the forward staged for that quad before all its pixels
+        // saturated -- the touch byte of that quad is DEFINED for exactly those entries (nothing behind them was blended,
+        // nothing is written there): the backward's bookkeeping visits the walked prefix of a list, not all of it
+        covered = o;    o += gsr_align(size_t(tiles) * 16);
         // one byte per (sorted instance, quad): did the forward blend it into >= 1 pixel of that quad?
         // The backward evaluates exactly those pairs (everything else has zero gradient).
         touch = o;      o += gsr_align(size_t(D) * 4);
@@ -108,9 +112,11 @@ int gsr_exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t*
                            void* ws, hipStream_t s);
 int gsr_exclusive_scan_u8(const uint8_t* in, uint32_t* out, int64_t n, void* ws, hipStream_t s);
 size_t gsr_sort_ws_bytes(int64_t n);
+// vals2_*: optional second value array carried with the pairs (NULL: none)
 int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
                          uint32_t* vals_out, uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n,
-                         int begin_bit, int end_bit, void* ws, hipStream_t s);
+                         int begin_bit, int end_bit, void* ws, hipStream_t s,
+                         const uint32_t* vals2_in = nullptr, uint32_t* vals2_out = nullptr, uint32_t* vals2_tmp = nullptr);
 
 // ---------------------------------------------------------------- kernel launchers
 int gsr_launch_preprocess_fwd(const GsrView& v, const GsrGaussians& g, float* splat,
@@ -122,15 +128,14 @@ int gsr_launch_rank_gather(int N, const uint32_t* order, const uint2* tile_rect,
                            hipStream_t s);
 int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const uint32_t* offs,
                     const uint2* rank_rect, uint32_t* tile_keys, uint32_t* emit_gid, hipStream_t s);
-int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted,
-                             const uint32_t* inst_row, const uint32_t* emit_gid,
-                             uint32_t* point_list, uint32_t* ranges, hipStream_t s);
+int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted, uint32_t* ranges, hipStream_t s);
 int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* splat,
                           float* final_T, uint32_t* n_contrib, float* out_color,
-                          float* out_allmap, uint8_t* touch, const float* feat, const uint32_t* point_list,
+                          float* out_allmap, uint8_t* touch, uint32_t* covered, const float* feat, const uint32_t* point_list,
                           hipStream_t s);
-int gsr_launch_slot_count(int D, const uint32_t* touch, const uint32_t* inst_row, uint8_t* cnt, hipStream_t s);
-int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* inst_row,
+int gsr_launch_slot_count(int D, int n_tiles, const uint32_t* ranges, const uint32_t* covered, const uint32_t* touch,
+                          const uint32_t* inst_row, uint8_t* cnt, hipStream_t s);
+int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* covered, const uint32_t* inst_row,
                           const float* splat, const uint32_t* touch, const uint32_t* slot_off, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
                           const float* feat, const uint32_t* point_list, float* feat_rows, hipStream_t s);

@@ -37,39 +37,98 @@ struct PreBwdParams {
 // a Gaussian are one contiguous run of 80-byte rows.  Lanes 0..14 read it three rows (240 contiguous bytes) per
 // round, four rounds in flight: lane s always handles 16-byte column group s % 5 of row 3k + s / 5.  Two DPP
 // shifts then add the three lanes that share a column group.  Fixed order => bitwise reproducible gradients.
+//
+// Load balance: a splat that fills the screen owns tens of thousands of rows (one per 4x4 block it was blended into),
+// and 16 lanes walking them 12 at a time would hold the whole kernel hostage (measured: 1 M splats of 24 px mean radius,
+// after 400 training steps reduce_rows 0.35 -> 5.6 ms per launch).  A Gaussian with more than RR_BIG rows is therefore
+// only NOTED by its 16 lanes (LDS list, at most 16 per workgroup) and summed afterwards by the WHOLE 256-thread
+// workgroup: group g takes rounds g, g + 16, ... of three rows, the 16 partial sums are combined through LDS in group
+// order.  The assignment of rows to lanes is fixed, so gradients stay bitwise reproducible.
+#define RR_BIG 192
+#define RR_GROUPS 16
 __global__ void __launch_bounds__(256) reduce_rows_kernel(int N, const uint32_t* __restrict__ order,
                                                           const uint32_t* __restrict__ offs,
                                                           const uint32_t* __restrict__ slot_off,
                                                           const float4* __restrict__ rows,
                                                           float4* __restrict__ sums) {
+    __shared__ uint32_t s_big[RR_GROUPS];
+    __shared__ int s_nbig;
+    __shared__ float4 s_part[RR_GROUPS][5];
+    if (threadIdx.x == 0) s_nbig = 0;
+    __syncthreads();
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = (int)(t >> 4), s16 = (int)(t & 15);
-    const bool valid = r < N && s16 < 15;
+    const int r = (int)(t >> 4), s16 = (int)(t & 15), group = (int)(threadIdx.x >> 4);
+    bool valid = r < N && s16 < 15;
     uint32_t s0 = 0, s1 = 0;
-    if (valid) { s0 = slot_off[offs[r]]; s1 = slot_off[offs[r + 1]]; }
-    const int n_rows = (int)(s1 - s0);
+    if (r < N) { s0 = slot_off[offs[r]]; s1 = slot_off[offs[r + 1]]; }
+    int n_rows = (int)(s1 - s0);
+    if (n_rows > RR_BIG) {            // (uniform over the 16 lanes of the Gaussian)
+        if (s16 == 0) s_big[atomicAdd(&s_nbig, 1)] = (uint32_t)r;
+        valid = false;
+    }
+    if (!valid) n_rows = 0;
     const int sub0 = s16 / 5;                       // 0..2: row inside the round
-    const float4* src = rows + (size_t)s0 * 5 + s16;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k0 = 0; 3 * k0 < n_rows; k0 += 4) {
-        float4 v[4];
+    {
+        const float4* src = rows + (size_t)s0 * 5 + s16;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k0 = 0; 3 * k0 < n_rows; k0 += 4) {
+            float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (3 * (k0 + u) + sub0 < n_rows) v[u] = src[15 * (k0 + u)];
+            for (int u = 0; u < 4; ++u) {
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (3 * (k0 + u) + sub0 < n_rows) v[u] = src[15 * (k0 + u)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
+        // all 64 lanes reach this point.  Lanes s, s + 5, s + 10 hold the same column group.
+        float o[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        for (int c = 0; c < 4; ++c) {
+            const float a5 = dpp_move<0x115, 0xf>(o[c]);    // row_shr:5  (lane s receives lane s - 5)
+            const float a10 = dpp_move<0x11A, 0xf>(o[c]);   // row_shr:10
+            o[c] = (o[c] + a5) + a10;
+        }
+        if (valid && s16 >= 10) sums[(size_t)order[r] * 5 + (s16 - 10)] = make_float4(o[0], o[1], o[2], o[3]);
     }
-    // all 64 lanes reach this point.  Lanes s, s + 5, s + 10 hold the same column group.
-    float o[4] = {acc.x, acc.y, acc.z, acc.w};
+    __syncthreads();
+    const int nbig = s_nbig;          // uniform over the workgroup; 0 for almost every workgroup of an ordinary frame
+    for (int b = 0; b < nbig; ++b) {
+        const uint32_t rb = s_big[b];
+        const uint32_t b0 = slot_off[offs[rb]], b1 = slot_off[offs[rb + 1]];
+        const int nr = s16 < 15 ? (int)(b1 - b0) : 0;
+        const float4* src = rows + (size_t)b0 * 5 + s16;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k0 = group; 3 * k0 < nr; k0 += 4 * RR_GROUPS) {
+            float4 v[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float a5 = dpp_move<0x115, 0xf>(o[c]);    // row_shr:5  (lane s receives lane s - 5)
-        const float a10 = dpp_move<0x11A, 0xf>(o[c]);   // row_shr:10
-        o[c] = (o[c] + a5) + a10;
+            for (int u = 0; u < 4; ++u) {
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int k = k0 + u * RR_GROUPS;
+                if (3 * k + sub0 < nr) v[u] = src[(size_t)15 * k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float a5 = dpp_move<0x115, 0xf>(o[c]);
+            const float a10 = dpp_move<0x11A, 0xf>(o[c]);
+            o[c] = (o[c] + a5) + a10;
+        }
+        if (s16 >= 10 && s16 < 15) s_part[group][s16 - 10] = make_float4(o[0], o[1], o[2], o[3]);
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g = 0; g < RR_GROUPS; ++g) {
+                const float4 v = s_part[g][threadIdx.x];
+                tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+            }
+            sums[(size_t)order[rb] * 5 + threadIdx.x] = tot;
+        }
+        __syncthreads();
     }
-    if (valid && s16 >= 10) sums[(size_t)order[r] * 5 + (s16 - 10)] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* offs, const uint32_t* slot_off,

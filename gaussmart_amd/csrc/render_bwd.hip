@@ -49,7 +49,7 @@
 struct RenderBwdParams {
     int W, H, gx, n_tiles, per_xcd;
     uint32_t flags;
-    const uint32_t* ranges; const uint32_t* inst_row;
+    const uint32_t* ranges; const uint32_t* covered; const uint32_t* inst_row;
     const float4* splat; const uint32_t* touch; const uint32_t* slot_off; const float* bg;
     const float* final_T; const uint32_t* n_contrib;
     const float* dL_dcolor; const float* dL_dallmap;
@@ -69,6 +69,13 @@ __device__ __forceinline__ uint32_t rb_pack16(int lo, int hi) {
     uint32_t r;
     asm("s_pack_ll_b32_b16 %0, %1, %2" : "=s"(r) : "s"(lo), "s"(hi));
     return r;
+}
+
+// touch word of list position `pos` with the bytes of the quads that never staged that entry forced to zero
+__device__ __forceinline__ uint32_t rb_defined_touch(uint32_t word, uint32_t pos, const uint4 cov) {
+    const uint32_t m = (pos < cov.x ? 0x0000000Fu : 0u) | (pos < cov.y ? 0x00000F00u : 0u) |
+                       (pos < cov.z ? 0x000F0000u : 0u) | (pos < cov.w ? 0x0F000000u : 0u);
+    return word & m;
 }
 
 #ifndef RB_MIN_WAVES
@@ -105,6 +112,8 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
 
     const uint32_t tile = (uint32_t)(tile_y * p.gx + tile_x);
     const uint32_t r0 = p.ranges[2 * tile];
+    // the forward wrote quad w's touch byte of a list entry only below covered[w] (wave-uniform)
+    const uint4 cov4 = *reinterpret_cast<const uint4*>(p.covered + 4 * tile);
 
     // the deepest list entry any pixel of THIS QUAD reached
     const int last_contributor = inside ? (int)p.n_contrib[pix_id] : 0;
@@ -175,7 +184,7 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
         ids_cur = lane < cnt ? p.point_list[r0 + lo + lane] : 0u;
         GSR_GATHER5(ids_cur, cnt);
         pf_row = lane < cnt ? p.inst_row[r0 + lo + lane] : 0u;
-        pf_touch = lane < cnt ? p.touch[(size_t)r0 + lo + lane] : 0u;
+        pf_touch = lane < cnt ? rb_defined_touch(p.touch[(size_t)r0 + lo + lane], (uint32_t)(lo + lane), cov4) : 0u;
         const int lo2 = max(0, lo - 64), cnt2 = lo - lo2;
         ids_nxt = lane < cnt2 ? p.point_list[r0 + lo2 + lane] : 0u;
     }
@@ -200,7 +209,7 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
             const int hi2 = lo, lo2 = max(0, hi2 - 64), cnt = hi2 - lo2;
             GSR_GATHER5(ids_nxt, cnt);
             pf_row = lane < cnt ? p.inst_row[r0 + lo2 + lane] : 0u;
-            pf_touch = lane < cnt ? p.touch[(size_t)r0 + lo2 + lane] : 0u;
+            pf_touch = lane < cnt ? rb_defined_touch(p.touch[(size_t)r0 + lo2 + lane], (uint32_t)(lo2 + lane), cov4) : 0u;
             ids_cur = ids_nxt;
             const int lo3 = max(0, lo2 - 64), cnt3 = lo2 - lo3;
             ids_nxt = lane < cnt3 ? p.point_list[r0 + lo3 + lane] : 0u;
@@ -374,20 +383,32 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
 
 // Gradient rows are dense: instance e owns rows [slot_off[e], slot_off[e + 1]), one per 4x4 block the forward
 // blended it into.  Count them per instance (touch word -> popcount, scattered to the emission index).
-// The counts (<= 16) are BYTES: the scatter is random at element granularity, and every partially written line
-// leaves the L2 as a full-line transaction -- into a D-byte array (3 MB at 1M / 1080p, L2-resident) instead of a
-// 4D-byte one that is 90 MB of HBM writes for 13 MB of payload (PMC WRITE_SIZE) less.
-__global__ void __launch_bounds__(256) slot_count_kernel(int D, const uint32_t* __restrict__ touch,
+// One workgroup per TILE walks the prefix of its list that at least one quad staged (covered): everything behind it was
+// occluded, has no rows, and keeps the 0 of the memset -- at D = 20 M with 300-500 entries walked per pixel that is a
+// quarter of the instances.  The counts (<= 16) are BYTES: the scatter is random at element granularity, and every
+// partially written line leaves the L2 as a full-line transaction -- into a D-byte array (L2-resident) instead of a
+// 4D-byte one.
+__global__ void __launch_bounds__(256) slot_count_kernel(int n_tiles, const uint32_t* __restrict__ ranges,
+                                                         const uint32_t* __restrict__ covered,
+                                                         const uint32_t* __restrict__ touch,
                                                          const uint32_t* __restrict__ inst_row,
                                                          uint8_t* __restrict__ cnt) {
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos < D) cnt[inst_row[pos]] = (uint8_t)__popc(touch[pos] & 0x0F0F0F0Fu);
+    const int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const uint32_t r0 = ranges[2 * tile];
+    const uint4 cov = *reinterpret_cast<const uint4*>(covered + 4 * tile);
+    const uint32_t walked = max(max(cov.x, cov.y), max(cov.z, cov.w));
+    for (uint32_t pos = threadIdx.x; pos < walked; pos += 256) {
+        const uint32_t w = rb_defined_touch(touch[(size_t)r0 + pos], pos, cov);
+        cnt[inst_row[(size_t)r0 + pos]] = (uint8_t)__popc(w);
+    }
 }
 
-int gsr_launch_slot_count(int D, const uint32_t* touch, const uint32_t* inst_row, uint8_t* cnt, hipStream_t s) {
+int gsr_launch_slot_count(int D, int n_tiles, const uint32_t* ranges, const uint32_t* covered, const uint32_t* touch,
+                          const uint32_t* inst_row, uint8_t* cnt, hipStream_t s) {
     if (D <= 0) return GSR_OK;
-    GsrProfileScope prof(GSR_K_SCAN, s);
-    hipLaunchKernelGGL(slot_count_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, D, touch, inst_row, cnt);
+    GsrProfileScope prof(GSR_K_SCAN, s);      // (cnt is zeroed by the caller)
+    hipLaunchKernelGGL(slot_count_kernel, dim3((unsigned)n_tiles), dim3(256), 0, s, n_tiles, ranges, covered, touch, inst_row, cnt);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }
@@ -425,7 +446,7 @@ int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint3
     return GSR_OK;
 }
 
-int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* inst_row,
+int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* covered, const uint32_t* inst_row,
                           const float* splat, const uint32_t* touch, const uint32_t* slot_off, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
                           const float* feat, const uint32_t* point_list, float* feat_rows, hipStream_t s) {
@@ -433,7 +454,7 @@ int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32
     p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
     p.flags = v.flags;
-    p.ranges = ranges; p.inst_row = inst_row; p.splat = reinterpret_cast<const float4*>(splat); p.touch = touch;
+    p.ranges = ranges; p.covered = covered; p.inst_row = inst_row; p.splat = reinterpret_cast<const float4*>(splat); p.touch = touch;
     p.slot_off = slot_off; p.bg = v.bg;
     p.final_T = final_T; p.n_contrib = n_contrib; p.dL_dcolor = dL_dcolor; p.dL_dallmap = dL_dallmap;
     p.grad_rows = grad_rows;

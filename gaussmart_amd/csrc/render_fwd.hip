@@ -41,7 +41,7 @@ struct RenderFwdParams {
     const uint32_t* ranges; const float4* splat;   // splat table [N] x 5 float4, gathered by id
     const float* bg;
     float* final_T; uint32_t* n_contrib; float* out_color; float* out_allmap;
-    uint8_t* touch;
+    uint8_t* touch; uint32_t* covered;
     // wide payload (FEAT16 > 0): C = 4..64 feature channels per Gaussian instead of the RGB of the record
     const float* feat; const uint32_t* point_list; int C;
 };
@@ -231,10 +231,10 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
         __builtin_amdgcn_wave_barrier();   // all reads of this batch precede the next batch's LDS writes
     }
 
-    // entries behind the point where every pixel saturated were never staged: nothing was blended there
-    // (the backward sizes its gradient rows from these bytes, so they must all be defined)
-    if (SAVE)
-        for (int pos = covered + lane; pos < n_list; pos += 64) p.touch[((size_t)r0 + pos) * 4 + wave] = 0;
+    // entries behind the point where every pixel saturated were never staged: nothing was blended there and their touch
+    // bytes stay UNWRITTEN -- the backward reads this quad's byte only below `covered` (with thousands of occluded
+    // entries per tile, zero-filling them cost more store traffic than the compositing itself)
+    if (SAVE && lane == 0) p.covered[tile * 4 + wave] = (uint32_t)covered;
 
     if (inside) {
         if (SAVE) {
@@ -265,14 +265,14 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
 
 int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* splat,
                           float* final_T, uint32_t* n_contrib, float* out_color,
-                          float* out_allmap, uint8_t* touch, const float* feat, const uint32_t* point_list,
+                          float* out_allmap, uint8_t* touch, uint32_t* covered, const float* feat, const uint32_t* point_list,
                           hipStream_t s) {
     RenderFwdParams p;
     p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE; p.flags = v.flags;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
     p.ranges = ranges; p.splat = reinterpret_cast<const float4*>(splat); p.bg = v.bg;
     p.final_T = final_T; p.n_contrib = n_contrib; p.out_color = out_color; p.out_allmap = out_allmap;
-    p.touch = touch; p.feat = feat; p.point_list = point_list; p.C = v.channels;
+    p.touch = touch; p.covered = covered; p.feat = feat; p.point_list = point_list; p.C = v.channels;
     if (p.gx <= 0 || gy <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_RENDER_FWD, s);
     p.n_tiles = p.gx * gy; p.per_xcd = (p.n_tiles + 7) / 8;

@@ -288,3 +288,33 @@ def test_benchmark_frame_tile_restricted_backward_vs_oracle(gpu_device):
               f"fp32: normwise {normwise32:.2e}  median {med32:.2e}  p99 {p99_32:.2e}")
         assert normwise < 5e-3 and med < 1e-4 and p99 < 5e-3, (k, normwise, med, p99)
         assert med <= 2.0 * med32 + 1e-6 and p99 <= 3.0 * p99_32 + 1e-5, (k, med, med32, p99, p99_32)
+
+
+def test_backward_parity_screen_filling_splats(gpu_device):
+    """Splats that cover a large part of the frame own thousands of gradient rows each (one per 4x4 block they are
+    blended into): the row reduction hands every Gaussian with more than 192 rows to its whole workgroup
+    -- checked against the fp64 oracle, with faint splats so that every one of them is blended
+    far down the lists."""
+    n, w, h = 400, 176, 144
+    a, cam = _deep_scene(n, w, h, 45.0, 9, 0.0, 0.05)
+    g = torch.Generator().manual_seed(21)
+    wc, wa = torch.randn(3, h, w, generator=g), torch.randn(7, h, w, generator=g)
+    bg = (0.2, 0.4, 0.6)
+    gh, c_h, am_h, radii = _hip_grads(a, cam, gpu_device, 3, wc, wa, bg)
+    go, c_o, am_o, _, S = _oracle_grads(a, cam, 3, wc, wa, bg)
+    L = O.LAST
+    # rows per Gaussian ~ blocks it is blended into: count the blocks its rect covers as a lower-bound proxy
+    rect = L["geom"].rect.numpy().astype(np.int64)
+    blocks = ((rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1])) * 16
+    print(f"\n[screen-filling splats] tile-rect blocks per Gaussian: median {int(np.median(blocks))}, max {int(blocks.max())}; "
+          f"{int((blocks > 192).sum())} of {n} Gaussians above the 192-row hand-over")
+    assert int((blocks > 1000).sum()) > 50
+    assert float((c_h - c_o).abs().max()) < 5e-3
+    sens, _ = O.flip_sensitive_gaussians(*L["full_geom"], L["point_list"], L["ranges"], S, flags=3, tol=1e-3)
+    for k in gh:
+        rel, act, normwise = _row_stats(gh[k], go[k], n)
+        d = (gh[k] - go[k]).abs().reshape(n, -1).amax(1)
+        sc = float(go[k].abs().max())
+        print(f"    {k:10s} normwise {normwise:.2e}  median {float(rel[act].median()):.2e}  p99 {float(rel[act].quantile(0.99)):.2e}")
+        assert float(rel[act].median()) < 1e-4 and float(rel[act].quantile(0.99)) < 2e-3, k
+        assert int(((d > 2e-3 * sc) & ~sens).sum()) == 0, k
