@@ -202,8 +202,10 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
         if (STAGE_FEAT) {   // issued before the next batch's prefetch, so waiting for them does not wait for it
             const float4* fsrc = reinterpret_cast<const float4*>(p.feat + (size_t)id_of_lane * p.C);
 #pragma unroll
-            for (int k = 0; k < NQ; ++k)
+            for (int k = 0; k < NQ; ++k) {
+                ft[k] = zero4;
                 if (feat_needed && 4 * k < p.C) ft[k] = fsrc[k];
+            }
         }
         {   // prefetch the next (shallower) batch
             const int hi2 = lo, lo2 = max(0, hi2 - 64), cnt = hi2 - lo2;
@@ -215,9 +217,12 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
             ids_nxt = lane < cnt3 ? p.point_list[r0 + lo3 + lane] : 0u;
         }
         if (STAGE_FEAT) {
+            // EVERY slot is written (zeros where the features were not fetched): a block whose mask is empty this
+            // iteration evaluates a dummy entry with weight 0, and 0 x (stale LDS bits that happen to be NaN) would poison
+            // its suffix recursion
 #pragma unroll
             for (int k = 0; k < NQ; ++k)
-                if (feat_needed && 4 * k < p.C) s_feat[lane * NQ + k] = ft[k];
+                if (4 * k < p.C) s_feat[lane * NQ + k] = feat_needed ? ft[k] : zero4;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -415,22 +420,61 @@ int gsr_launch_slot_count(int D, int n_tiles, const uint32_t* ranges, const uint
 
 // Wide payload: add a Gaussian's feature rows (same dense slots as the geometry rows) in fixed order.  One thread
 // per (depth rank, 4-channel piece); writes dL_dcolors [N,C] by Gaussian id (zeros for Gaussians with no instance).
+// As in reduce_rows, a Gaussian with more than RF_BIG rows is noted (by its piece-0 thread) and summed afterwards by the
+// whole workgroup -- 256 / C4 row lanes per piece, partials combined through LDS in lane order -- instead of one thread
+// walking tens of thousands of rows.
+#define RF_BIG 192
 __global__ void __launch_bounds__(256) reduce_feat_rows_kernel(long long n_threads, int C4,
                                                                const uint32_t* __restrict__ order,
                                                                const uint32_t* __restrict__ offs,
                                                                const uint32_t* __restrict__ slot_off,
                                                                const float4* __restrict__ rows,
                                                                float4* __restrict__ out) {
+    __shared__ uint32_t s_big[256];
+    __shared__ int s_nbig;
+    __shared__ float4 s_part[256];
+    if (threadIdx.x == 0) s_nbig = 0;
+    __syncthreads();
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_threads) return;
-    const int r = (int)(t / C4), q = (int)(t - (long long)r * C4);
-    const uint32_t s0 = slot_off[offs[r]], s1 = slot_off[offs[r + 1]];
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t sl = s0; sl < s1; ++sl) {
-        const float4 v = rows[(size_t)sl * C4 + q];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    if (t < n_threads) {
+        const int r = (int)(t / C4), q = (int)(t - (long long)r * C4);
+        const uint32_t s0 = slot_off[offs[r]], s1 = slot_off[offs[r + 1]];
+        if (s1 - s0 > (uint32_t)RF_BIG) {
+            if (q == 0) s_big[atomicAdd(&s_nbig, 1)] = (uint32_t)r;
+        } else {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (uint32_t sl = s0; sl < s1; ++sl) {
+                const float4 v = rows[(size_t)sl * C4 + q];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            out[(size_t)order[r] * C4 + q] = acc;
+        }
     }
-    out[(size_t)order[r] * C4 + q] = acc;
+    __syncthreads();
+    const int nbig = s_nbig;                       // uniform over the workgroup
+    const int L = 256 / C4;                        // row lanes per piece
+    const int q = (int)threadIdx.x % C4, rl = (int)threadIdx.x / C4;
+    for (int b = 0; b < nbig; ++b) {
+        const uint32_t rb = s_big[b];
+        const uint32_t s0 = slot_off[offs[rb]], s1 = slot_off[offs[rb + 1]];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rl < L)
+            for (uint32_t sl = s0 + (uint32_t)rl; sl < s1; sl += (uint32_t)L) {
+                const float4 v = rows[(size_t)sl * C4 + q];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        s_part[threadIdx.x] = acc;
+        __syncthreads();
+        if ((int)threadIdx.x < C4) {
+            float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int l = 0; l < L; ++l) {
+                const float4 v = s_part[l * C4 + threadIdx.x];
+                tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+            }
+            out[(size_t)order[rb] * C4 + threadIdx.x] = tot;
+        }
+        __syncthreads();
+    }
 }
 
 int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint32_t* offs, const uint32_t* slot_off,

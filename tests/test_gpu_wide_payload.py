@@ -110,3 +110,21 @@ def test_wide_payload_nothing_visible(gpu_device):
     assert int((r > 0).sum()) == 0
     assert torch.equal(c, torch.tensor(bg, device=dev).view(-1, 1, 1).expand_as(c).contiguous())
     assert float(col.grad.abs().max()) == 0.0 and float(am.detach().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("C", [8, 24])
+def test_wide_payload_screen_filling_splats(gpu_device, C):
+    """Splats with thousands of gradient rows each: the feature-row reduction hands them to the whole workgroup
+    (reduce_feat_rows_kernel, like reduce_rows); checked against the oracle with faint splats, so every one of them is
+    blended far down the lists.  C = 24: 6 pieces per Gaussian, which does not divide the 256-thread workgroup."""
+    from test_gpu_deep_lists import _deep_scene
+    n, w, h = 300, 160, 128
+    a, cam = _deep_scene(n, w, h, 45.0, 12, 0.0, 0.05)
+    g = torch.Generator().manual_seed(C)
+    b = dict(means3D=a["means3D"], opacities=a["opacities"], scales=a["scales"], rotations=a["rotations"],
+             colors_precomp=torch.randn(n, C, generator=g))
+    bg = tuple(float(x) for x in torch.rand(C, generator=g))
+    stats, (c_h, c_o) = _grad_compare(b, cam, gpu_device, 3, bg=bg)
+    assert float((c_h.double() - c_o.detach()).abs().max()) < 5e-3 * max(1.0, float(c_o.detach().abs().max()))
+    for k, s in stats.items():
+        assert s["median"] < 1e-4 and s["p99"] < 2e-3, (k, s)
