@@ -203,6 +203,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     uint32_t* tiles_touched = at<uint32_t>(geom, GL.tiles_touched);
     uint2* tile_rect = at<uint2>(geom, GL.tile_rect);
     uint32_t* depth_key = at<uint32_t>(geom, GL.depth_key);
+    float* color_jac = fwd_only ? nullptr : at<float>(geom, GL.color_jac);   // (only a backward reads it)
 
     // N-sized scratch: depth-sort double buffers, sort + scan workspaces
     const size_t nb = gsr_align(size_t(N > 0 ? N : 1) * 4);
@@ -240,7 +241,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
                 if (!ev2) { gsr_set_error("hipEventCreate failed (colour-pass events)"); return GSR_E_HIP; }
                 GSR_HIP_CHECK(hipEventRecord(ev2[0], s));
                 GSR_HIP_CHECK(hipStreamWaitEvent(cs, ev2[0], 0));
-                rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, cs);
+                rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, color_jac, cs);
                 if (rc != GSR_OK) return rc;
                 GSR_HIP_CHECK(hipEventRecord(ev2[1], cs));
                 color_join.done = ev2[1]; color_join.armed = true;
@@ -265,7 +266,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         hipError_t e1 = hipMemcpyAsync(d_host, offs + N, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         hipError_t e2 = e1 == hipSuccess ? hipEventRecord(ev, s) : e1;
         if (!defer_color)
-            rc = e2 == hipSuccess ? gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, s) : GSR_OK;
+            rc = e2 == hipSuccess ? gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, color_jac, s) : GSR_OK;
         hipError_t e3 = e2 == hipSuccess ? hipEventSynchronize(ev) : e2;   // the one host wait of the forward
         (void)hipEventDestroy(ev);
         GSR_HIP_CHECK(e3);
@@ -314,7 +315,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         GSR_HIP_CHECK(hipStreamWaitEvent(s, color_join.done, 0));
     } else if (defer_color && N > 0) {   // binning did not need the colours: announce the pass, then enqueue it
         if (!alloc(ctx, GSR_BUF_SYNC_SH, 0)) { gsr_set_error("allocator refused GSR_BUF_SYNC_SH"); return GSR_E_ALLOC; }
-        rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, s);
+        rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, color_jac, s);
         if (rc != GSR_OK) return rc;
     }
     return gsr_launch_render_fwd(*view, ranges, splat, fwd_only ? nullptr : at<float>(image, IL.final_T),
@@ -431,7 +432,7 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
         o.dL_dcolors = nullptr;
     }
     return gsr_launch_preprocess_bwd(*view, *g, radii, at<float>(geom, GL.splat), at<uint32_t>(geom, GL.clamped),
-                                     row_sums, o, s);
+                                     row_sums, at<float>(geom, GL.color_jac), o, s);
 }
 
 // ------------------------------------------------------------------------------- introspection

@@ -64,7 +64,7 @@ struct GsrProfileScope {
 static inline size_t gsr_align(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct GsrGeomLayout {
-    size_t splat, clamped, tiles_touched, tile_rect, depth_key, order, offs, total;
+    size_t splat, clamped, tiles_touched, tile_rect, depth_key, order, offs, color_jac, total;
     explicit GsrGeomLayout(int64_t N) {
         size_t o = 0;
         splat = o;         o += gsr_align(size_t(N) * GSR_SPLAT_FLOATS * 4);
@@ -74,6 +74,9 @@ struct GsrGeomLayout {
         depth_key = o;     o += gsr_align(size_t(N) * 4);
         order = o;         o += gsr_align(size_t(N) * 4);        // depth rank -> Gaussian id
         offs = o;          o += gsr_align(size_t(N + 1) * 4);    // depth rank -> first instance (emission order)
+        // d(rgb)/d(view direction), 3x3 per Gaussian, left by the SH colour pass so that preprocess_bwd does not have to
+        // read the 192 bytes of SH coefficients again for the view-direction term of dL/dmean
+        color_jac = o;     o += gsr_align(size_t(N) * 9 * 4);
         total = o > 0 ? o : 256;
     }
 };
@@ -123,7 +126,9 @@ int gsr_launch_preprocess_fwd(const GsrView& v, const GsrGaussians& g, float* sp
                               uint32_t* clamped, uint32_t* tiles_touched, uint2* tile_rect, uint32_t* depth_key,
                               int32_t* radii, hipStream_t s);
 int gsr_launch_preprocess_color(const GsrView& v, const GsrGaussians& g, float* splat, uint32_t* clamped,
-                                int32_t* radii, hipStream_t s);
+                                int32_t* radii, float* color_jac /* [N,9] or NULL */, hipStream_t s);
+// does the colour pass of this call leave d(rgb)/d(dir) (forward and backward must agree)?
+bool gsr_color_jac_available(const GsrView& v, const GsrGaussians& g);
 int gsr_launch_rank_gather(int N, const uint32_t* order, const uint2* tile_rect, uint2* rank_rect, uint32_t* rank_cnt,
                            hipStream_t s);
 int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const uint32_t* offs,
@@ -145,7 +150,7 @@ int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* offs, c
                            const float* grad_rows, float* row_sums, hipStream_t s);
 int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int32_t* radii,
                               const float* splat, const uint32_t* clamped, const float* row_sums,
-                              const GsrGrads& out, hipStream_t s);
+                              const float* color_jac /* [N,9] or NULL */, const GsrGrads& out, hipStream_t s);
 
 // ---------------------------------------------------------------- small device helpers
 #ifdef __HIPCC__

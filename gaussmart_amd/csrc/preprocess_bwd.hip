@@ -29,6 +29,7 @@ struct PreBwdParams {
     const float* tprecomp;
     const int32_t* radii; const float* splat; const uint32_t* clamped;
     const float* row_sums;
+    const float* jac;   // d(rgb)/d(dir) [N,9] left by the colour pass (factored mode: the SH coefficients are then not read at all)
     GsrGrads out;
 };
 
@@ -157,6 +158,7 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
     float* my_sh = wl + lane * SH_ROW_FLOATS;
     if (STAGE_SH)
         sh_stage<true>(wl, const_cast<float*>(p.shs), const_cast<float*>(p.shs_rest), p.M, wave_first, n_here, lane);
+    const bool use_jac = !STAGE_SH && p.jac != nullptr;
 
     const bool valid = idx < p.N;
     const bool visible = valid && p.radii[idx] > 0;
@@ -291,51 +293,59 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
             const float oz = p.means[3 * idx + 2] - p.campos[2];
             const float il = 1.0f / sqrtf(ox * ox + oy * oy + oz * oz);
             const float x = ox * il, y = oy * il, z = oz * il;
-            const int deg = p.deg;
-            float dbx[16], dby[16], dbz[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { dbx[k] = 0.f; dby[k] = 0.f; dbz[k] = 0.f; }
-            basis[0] = GSR_SH_C0;
-            if (deg > 0) {
-                basis[1] = -GSR_SH_C1 * y; basis[2] = GSR_SH_C1 * z; basis[3] = -GSR_SH_C1 * x;
-                dby[1] = -GSR_SH_C1; dbz[2] = GSR_SH_C1; dbx[3] = -GSR_SH_C1;
-                if (deg > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    basis[4] = GSR_SH_C2_0 * xy; basis[5] = GSR_SH_C2_1 * yz;
-                    basis[6] = GSR_SH_C2_2 * (2.f * zz - xx - yy);
-                    basis[7] = GSR_SH_C2_3 * xz; basis[8] = GSR_SH_C2_4 * (xx - yy);
-                    dbx[4] = GSR_SH_C2_0 * y; dby[4] = GSR_SH_C2_0 * x;
-                    dby[5] = GSR_SH_C2_1 * z; dbz[5] = GSR_SH_C2_1 * y;
-                    dbx[6] = GSR_SH_C2_2 * -2.f * x; dby[6] = GSR_SH_C2_2 * -2.f * y; dbz[6] = GSR_SH_C2_2 * 4.f * z;
-                    dbx[7] = GSR_SH_C2_3 * z; dbz[7] = GSR_SH_C2_3 * x;
-                    dbx[8] = GSR_SH_C2_4 * 2.f * x; dby[8] = GSR_SH_C2_4 * -2.f * y;
-                    if (deg > 2) {
-                        basis[9] = GSR_SH_C3_0 * y * (3.f * xx - yy);
-                        basis[10] = GSR_SH_C3_1 * xy * z;
-                        basis[11] = GSR_SH_C3_2 * y * (4.f * zz - xx - yy);
-                        basis[12] = GSR_SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
-                        basis[13] = GSR_SH_C3_4 * x * (4.f * zz - xx - yy);
-                        basis[14] = GSR_SH_C3_5 * z * (xx - yy);
-                        basis[15] = GSR_SH_C3_6 * x * (xx - 3.f * yy);
-                        dbx[9] = GSR_SH_C3_0 * 6.f * xy; dby[9] = GSR_SH_C3_0 * (3.f * xx - 3.f * yy);
-                        dbx[10] = GSR_SH_C3_1 * yz; dby[10] = GSR_SH_C3_1 * xz; dbz[10] = GSR_SH_C3_1 * xy;
-                        dbx[11] = GSR_SH_C3_2 * -2.f * xy; dby[11] = GSR_SH_C3_2 * (4.f * zz - xx - 3.f * yy); dbz[11] = GSR_SH_C3_2 * 8.f * yz;
-                        dbx[12] = GSR_SH_C3_3 * -6.f * xz; dby[12] = GSR_SH_C3_3 * -6.f * yz; dbz[12] = GSR_SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy);
-                        dbx[13] = GSR_SH_C3_4 * (4.f * zz - 3.f * xx - yy); dby[13] = GSR_SH_C3_4 * -2.f * xy; dbz[13] = GSR_SH_C3_4 * 8.f * xz;
-                        dbx[14] = GSR_SH_C3_5 * 2.f * xz; dby[14] = GSR_SH_C3_5 * -2.f * yz; dbz[14] = GSR_SH_C3_5 * (xx - yy);
-                        dbx[15] = GSR_SH_C3_6 * (3.f * xx - 3.f * yy); dby[15] = GSR_SH_C3_6 * -6.f * xy;
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+            if (use_jac) {
+                // dL/ddir = g^T J with J = d(rgb)/d(dir) from the colour pass: 36 bytes instead of the 192 of the coefficients
+                const float* J = p.jac + (size_t)idx * 9;
+                ddx = g[0] * J[0] + g[1] * J[3] + g[2] * J[6];
+                ddy = g[0] * J[1] + g[1] * J[4] + g[2] * J[7];
+                ddz = g[0] * J[2] + g[1] * J[5] + g[2] * J[8];
+            } else {
+                const int deg = p.deg;
+                float dbx[16], dby[16], dbz[16];
+    #pragma unroll
+                for (int k = 0; k < 16; ++k) { dbx[k] = 0.f; dby[k] = 0.f; dbz[k] = 0.f; }
+                basis[0] = GSR_SH_C0;
+                if (deg > 0) {
+                    basis[1] = -GSR_SH_C1 * y; basis[2] = GSR_SH_C1 * z; basis[3] = -GSR_SH_C1 * x;
+                    dby[1] = -GSR_SH_C1; dbz[2] = GSR_SH_C1; dbx[3] = -GSR_SH_C1;
+                    if (deg > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        basis[4] = GSR_SH_C2_0 * xy; basis[5] = GSR_SH_C2_1 * yz;
+                        basis[6] = GSR_SH_C2_2 * (2.f * zz - xx - yy);
+                        basis[7] = GSR_SH_C2_3 * xz; basis[8] = GSR_SH_C2_4 * (xx - yy);
+                        dbx[4] = GSR_SH_C2_0 * y; dby[4] = GSR_SH_C2_0 * x;
+                        dby[5] = GSR_SH_C2_1 * z; dbz[5] = GSR_SH_C2_1 * y;
+                        dbx[6] = GSR_SH_C2_2 * -2.f * x; dby[6] = GSR_SH_C2_2 * -2.f * y; dbz[6] = GSR_SH_C2_2 * 4.f * z;
+                        dbx[7] = GSR_SH_C2_3 * z; dbz[7] = GSR_SH_C2_3 * x;
+                        dbx[8] = GSR_SH_C2_4 * 2.f * x; dby[8] = GSR_SH_C2_4 * -2.f * y;
+                        if (deg > 2) {
+                            basis[9] = GSR_SH_C3_0 * y * (3.f * xx - yy);
+                            basis[10] = GSR_SH_C3_1 * xy * z;
+                            basis[11] = GSR_SH_C3_2 * y * (4.f * zz - xx - yy);
+                            basis[12] = GSR_SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                            basis[13] = GSR_SH_C3_4 * x * (4.f * zz - xx - yy);
+                            basis[14] = GSR_SH_C3_5 * z * (xx - yy);
+                            basis[15] = GSR_SH_C3_6 * x * (xx - 3.f * yy);
+                            dbx[9] = GSR_SH_C3_0 * 6.f * xy; dby[9] = GSR_SH_C3_0 * (3.f * xx - 3.f * yy);
+                            dbx[10] = GSR_SH_C3_1 * yz; dby[10] = GSR_SH_C3_1 * xz; dbz[10] = GSR_SH_C3_1 * xy;
+                            dbx[11] = GSR_SH_C3_2 * -2.f * xy; dby[11] = GSR_SH_C3_2 * (4.f * zz - xx - 3.f * yy); dbz[11] = GSR_SH_C3_2 * 8.f * yz;
+                            dbx[12] = GSR_SH_C3_3 * -6.f * xz; dby[12] = GSR_SH_C3_3 * -6.f * yz; dbz[12] = GSR_SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy);
+                            dbx[13] = GSR_SH_C3_4 * (4.f * zz - 3.f * xx - yy); dby[13] = GSR_SH_C3_4 * -2.f * xy; dbz[13] = GSR_SH_C3_4 * 8.f * xz;
+                            dbx[14] = GSR_SH_C3_5 * 2.f * xz; dby[14] = GSR_SH_C3_5 * -2.f * yz; dbz[14] = GSR_SH_C3_5 * (xx - yy);
+                            dbx[15] = GSR_SH_C3_6 * (3.f * xx - 3.f * yy); dby[15] = GSR_SH_C3_6 * -6.f * xy;
+                        }
                     }
                 }
-            }
-            // dL/ddir = sum_c g_c * sum_k dbasis_k * sh[k][c]
-            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-            const int nk = (deg + 1) * (deg + 1);
-            const float* shp = STAGE_SH ? my_sh : p.shs + (size_t)idx * row_f;
-#pragma unroll
-            for (int k = 1; k < 16; ++k) {
-                if (k < nk && k < p.M) {
-                    const float w = g[0] * shp[3 * k] + g[1] * shp[3 * k + 1] + g[2] * shp[3 * k + 2];
-                    ddx += dbx[k] * w; ddy += dby[k] * w; ddz += dbz[k] * w;
+                // dL/ddir = sum_c g_c * sum_k dbasis_k * sh[k][c]
+                const int nk = (deg + 1) * (deg + 1);
+                const float* shp = STAGE_SH ? my_sh : p.shs + (size_t)idx * row_f;
+    #pragma unroll
+                for (int k = 1; k < 16; ++k) {
+                    if (k < nk && k < p.M) {
+                        const float w = g[0] * shp[3 * k] + g[1] * shp[3 * k + 1] + g[2] * shp[3 * k + 2];
+                        ddx += dbx[k] * w; ddy += dby[k] * w; ddz += dbz[k] * w;
+                    }
                 }
             }
             // through the normalisation dir = o / |o|
@@ -406,7 +416,7 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
 
 int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int32_t* radii,
                               const float* splat, const uint32_t* clamped,
-                              const float* row_sums, const GsrGrads& out, hipStream_t s) {
+                              const float* row_sums, const float* color_jac, const GsrGrads& out, hipStream_t s) {
     if (g.count <= 0) return GSR_OK;
     PreBwdParams p;
     p.N = g.count; p.W = v.width; p.H = v.height; p.deg = v.sh_degree; p.M = v.sh_coeffs;
@@ -417,12 +427,14 @@ int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int
     p.means = g.means3D; p.shs = g.shs; p.shs_rest = g.shs_rest; p.opac = g.opacities; p.scales = g.scales; p.rots = g.rotations;
     p.tprecomp = g.transmat_precomp; p.radii = radii; p.splat = splat; p.clamped = clamped;
     p.row_sums = row_sums; p.out = out;
+    // factored mode + Jacobian from the colour pass: no SH read, no SH write, no LDS
+    p.jac = (p.factored && gsr_color_jac_available(v, g)) ? color_jac : nullptr;
     const int blocks = (g.count + PB_BLOCK - 1) / PB_BLOCK;
     GsrProfileScope prof(GSR_K_PREPROCESS_BWD, s);
     const bool stage = sh_can_stage(g.shs, g.shs_rest, v.sh_coeffs) &&
                        (p.factored || sh_can_stage(out.dL_dshs, out.dL_dshs_rest, v.sh_coeffs));
     if (g.shs_rest && (!stage || (!p.factored && !out.dL_dshs_rest))) { gsr_set_error("split SH storage needs 16-byte aligned pointers, <= 16 coefficients and dL_dshs_rest"); return GSR_E_UNSUPPORTED; }
-    if (stage) {
+    if (stage && p.jac == nullptr) {
         const size_t lds_bytes = (size_t)(PB_BLOCK / 64) * 64 * SH_ROW_FLOATS * sizeof(float);
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(PB_BLOCK), lds_bytes, s, p);
     } else {

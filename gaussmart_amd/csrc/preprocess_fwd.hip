@@ -25,6 +25,7 @@ struct PreParams {
     const float* means; const float* shs; const float* shs_rest; const float* colors; const float* opac;
     const float* scales; const float* rots; const float* tprecomp;
     float* splat; uint32_t* clamped; uint32_t* tiles; uint2* rect; uint32_t* dkey; int32_t* radii;
+    float* jac;      // colour pass: d(rgb)/d(dir) [N,9] (row c = channel, column a = x, y, z), or NULL
 };
 
 __device__ __forceinline__ float3 sh_to_rgb(int deg, const float* sh /*[M][3] in LDS or global*/,
@@ -311,9 +312,33 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_color16_kernel(PreParams
         const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
         const float x = dx * il, y = dy * il, z = dz * il;
         const float poly = fmaf(b.al, x * x, fmaf(b.be, y * y, fmaf(b.ga, z * z, b.de)));
-        const float mono = fmaf(b.fx, x, ofx) * fmaf(b.fy, y, ofy) * fmaf(b.fz, z, ofz);
-        const float bk = radius[u] > 0 ? b.C * mono * poly : 0.f;     // (culled: il may be anything)
+        const float ux = fmaf(b.fx, x, ofx), uy = fmaf(b.fy, y, ofy), uz = fmaf(b.fz, z, ofz);
+        const float mono = ux * uy * uz;
+        const bool vis = radius[u] > 0;
+        const float bk = vis ? b.C * mono * poly : 0.f;     // (culled: il may be anything)
         float v[3] = {bk * s0[u], bk * s1[u], bk * s2[u]};
+        if (p.jac != nullptr) {
+            // d(basis_k)/d(dir) of the same product form, and with it J[c][a] = sum_k d(basis_k)/d(dir_a) * sh[k][c]: what
+            // preprocess_bwd needs for the view-direction term of dL/dmean, so that it does not read the SH coefficients again
+            const float cm = b.C * mono, cp_ = b.C * poly;
+            const float dbx = vis ? fmaf(cp_, b.fx * uy * uz, cm * 2.f * b.al * x) : 0.f;
+            const float dby = vis ? fmaf(cp_, b.fy * ux * uz, cm * 2.f * b.be * y) : 0.f;
+            const float dbz = vis ? fmaf(cp_, b.fz * ux * uy, cm * 2.f * b.ga * z) : 0.f;
+            float j[9] = {dbx * s0[u], dby * s0[u], dbz * s0[u], dbx * s1[u], dby * s1[u], dbz * s1[u],
+                          dbx * s2[u], dby * s2[u], dbz * s2[u]};
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                j[q] += dpp_move<0xB1, 0xf>(j[q]);
+                j[q] += dpp_move<0x4E, 0xf>(j[q]);
+                j[q] += dpp_move<0x141, 0xf>(j[q]);
+                j[q] += dpp_move<0x140, 0xf>(j[q]);
+            }
+            // every lane of the row holds the nine sums: lane q stores J[q] (36 contiguous bytes per Gaussian)
+            float mine = j[0];
+#pragma unroll
+            for (int q = 1; q < 9; ++q) mine = l16 == q ? j[q] : mine;
+            if (l16 < 9 && idx < p.N && vis) p.jac[(size_t)idx * 9 + l16] = mine;
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             v[c] += dpp_move<0xB1, 0xf>(v[c]);      // quad_perm [1,0,3,2]
@@ -345,13 +370,20 @@ static void fill_pre_params(PreParams& p, const GsrView& v, const GsrGaussians& 
     p.means = g.means3D; p.shs = g.shs; p.shs_rest = g.shs_rest; p.colors = v.channels == 3 ? g.colors_precomp : nullptr /* wide payloads are read by id in K6/K7 */; p.opac = g.opacities;
     p.scales = g.scales; p.rots = g.rotations; p.tprecomp = g.transmat_precomp;
     p.splat = splat; p.clamped = clamped; p.tiles = tiles_touched; p.rect = tile_rect; p.dkey = depth_key; p.radii = radii;
+    p.jac = nullptr;
+}
+
+bool gsr_color_jac_available(const GsrView& v, const GsrGaussians& g) {
+    // only the 16-lane register form of the colour pass computes it
+    return g.shs != nullptr && v.sh_coeffs <= 16 && !getenv("GSR_COLOR_STAGED");
 }
 
 int gsr_launch_preprocess_color(const GsrView& v, const GsrGaussians& g, float* splat, uint32_t* clamped,
-                                int32_t* radii, hipStream_t s) {
+                                int32_t* radii, float* color_jac, hipStream_t s) {
     if (g.count <= 0 || g.shs == nullptr) return GSR_OK;
     PreParams p;
     fill_pre_params(p, v, g, splat, clamped, nullptr, nullptr, nullptr, radii);
+    p.jac = gsr_color_jac_available(v, g) ? color_jac : nullptr;
     const int blocks = (g.count + PRE_BLOCK - 1) / PRE_BLOCK;
     GsrProfileScope prof(GSR_K_PREPROCESS_FWD, s);
     const bool stage = sh_can_stage(g.shs, g.shs_rest, v.sh_coeffs);

@@ -59,8 +59,12 @@ def test_record_rebuilds_the_sh_gradient(gpu_device, deg):
     n = p["xyz"].shape[0]
     assert rec is not None and rec.n == n and rec.record.numel() == 3 * n + 4
     assert p["features_dc"].grad is None and p["features_rest"].grad is None
-    for k in ("xyz", "opacity", "scaling", "rotation"):            # the geometry gradients are the same kernels
+    for k in ("opacity", "scaling", "rotation"):                   # the geometry gradients are the same kernels
         assert torch.equal(p[k].grad, ref[k]), k
+    # dL/dxyz: its view-direction term g^T d(rgb)/d(dir) is formed from the 3x3 Jacobian the colour pass left (factored:
+    # the SH coefficients are not read again) instead of from the coefficients themselves -- same sum, other order
+    dx = (p["xyz"].grad - ref["xyz"]).abs().max().item()
+    assert dx <= 1e-6 * ref["xyz"].abs().max().item() + 1e-12, dx
     assert torch.equal(rec.record[3 * n:3 * n + 3], cam.camera_center.to(gpu_device).float())
     g = rec.record[:3 * n].view(n, 3)
     assert torch.all(g[radii <= 0] == 0)                             # culled Gaussians carry no colour gradient
