@@ -297,8 +297,11 @@ def main():
         vp = ViewParallel(model, overlap_local=True)
 
     base_iter = 10_000
+    # the view of the next step is known (this rank always renders its own view): the SH optimiser step leaves its colours
+    # (gsr_adam_sh_factored_next), the next forward skips the SH colour pass.  GSR_BENCH_COLOR_CACHE=0: off (A/B aid)
+    next_cam = cam if os.environ.get("GSR_BENCH_COLOR_CACHE", "1") != "0" else None
     def step(i):
-        training_step(model, cam, gt, opt, pipe, bg, base_iter + i, view_parallel=vp)
+        training_step(model, cam, gt, opt, pipe, bg, base_iter + i, view_parallel=vp, next_cam=next_cam)
 
     log("target rendered; warm-up")
     if (vp is not None and os.environ.get("GSR_BENCH_HIGH_PRIORITY", "1") != "0") or os.environ.get("GSR_BENCH_HIGH_PRIORITY") == "1":

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (import order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GSR_LIB_PATH: developer aid for same-box A/B runs of two builds of the library (scripts/ab_builds.sh)
 LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(_HERE, "lib", "libgsr_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 GSR_BUF_GEOM, GSR_BUF_BINNING, GSR_BUF_IMAGE, GSR_BUF_SCRATCH, GSR_BUF_SCRATCH2 = range(5)
 GSR_BUF_SYNC_SH = 100     # not a buffer: "the SH colour pass is about to be enqueued" (GSR_FLAG_DEFER_COLOR)
@@ -28,6 +28,7 @@ GSR_FLAG_DEBUG_NO_CULL = 4
 GSR_FLAG_RAW_PARAMS = 8
 GSR_FLAG_DEFER_COLOR = 16
 GSR_FLAG_DEBUG_RECT_CULL_ONLY = 64
+GSR_FLAG_COLOR_CACHED = 256      # shs + colour cache of this view (gsr_adam_sh_factored_next): no SH colour pass
 GSR_FLAG_FORWARD_ONLY = 128      # inference: keep nothing for a backward (no touch words, no per-pixel state)
 GSR_FLAG_FACTORED_SH_GRAD = 32   # backward writes the masked colour gradient [N,3] instead of the SH gradient arrays
 
@@ -141,6 +142,9 @@ def lib():
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                            C.c_double, C.c_double, C.c_double, C.c_void_p]
+        L.gsr_adam_sh_factored_next.restype = C.c_int32
+        L.gsr_adam_sh_factored_next.argtypes = L.gsr_adam_sh_factored.argtypes[:-1] + [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                                                                       C.c_void_p, C.c_void_p]
         L.gsr_compact_workspace_bytes.restype = C.c_size_t
         L.gsr_compact_workspace_bytes.argtypes = [C.c_int64]
         L.gsr_compact_plan.restype = C.c_int32

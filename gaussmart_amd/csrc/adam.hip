@@ -123,11 +123,15 @@ struct AdamShParams {
     float* p_dc; float* m_dc; float* v_dc; float* p_rest; float* m_rest; float* v_rest;
     float ss_dc, ib_dc, ss_rest, ib_rest;
     float beta2, omb1, omb2, eps;
+    // gsr_adam_sh_factored_next: colour of the NEXT view from the coefficients just updated (NULL: plain step)
+    const float* xyz_next; const float* campos_next; int deg_next; int n_total; float* cache;
 };
 
 // Adam over the wave's n_f contiguous floats of one tensor starting at float offset `off`; element e belongs to tile
 // row e / row_f, column col0 + e % row_f.
-__device__ __forceinline__ void adam_sh_segment(const float* wl, int col0, int row_f, float* __restrict__ p,
+// KEEP: the updated parameter replaces the gradient in the tile, which then holds the wave's new coefficients.
+template <bool KEEP>
+__device__ __forceinline__ void adam_sh_segment(float* wl, int col0, int row_f, float* __restrict__ p,
                                                 float* __restrict__ m, float* __restrict__ v, long long off, int n_f,
                                                 float ss, float ib, const AdamShParams& a, int lane) {
     p += off; m += off; v += off;
@@ -154,6 +158,7 @@ __device__ __forceinline__ void adam_sh_segment(const float* wl, int col0, int r
                 for (int k = 0; k < 4; ++k) {
                     const float g = wl[r * AS_ROW + col0 + c];
                     adam_one(P[k], g, Mo[k], V[k], a.omb1, a.beta2, a.omb2, a.eps, ss, ib);
+                    if (KEEP) wl[r * AS_ROW + col0 + c] = P[k];
                     if (++c == row_f) { c = 0; ++r; }
                 }
                 reinterpret_cast<float4*>(p)[i] = pp[u];
@@ -166,10 +171,16 @@ __device__ __forceinline__ void adam_sh_segment(const float* wl, int col0, int r
         const int r = e / row_f, c = e - r * row_f;
         float pp = p[e], mm = m[e], vv = v[e];
         adam_one(pp, wl[r * AS_ROW + col0 + c], mm, vv, a.omb1, a.beta2, a.omb2, a.eps, ss, ib);
+        if (KEEP) wl[r * AS_ROW + col0 + c] = pp;
         p[e] = pp; m[e] = mm; v[e] = vv;
     }
 }
 
+// NEXT: after the update the wave evaluates, from the new coefficients still in its tile, the SH colour of the NEXT view
+// for its 64 Gaussians -- rgb (+0.5, clamped at 0), the clamp mask and d(rgb)/d(dir) -- into the colour cache the next
+// forward / backward read (GSR_FLAG_COLOR_CACHED): the 192 bytes per Gaussian the colour pass would read again are already
+// here.  Same formulas as preprocess_color16_kernel / utils/sh_utils.py:57-112.
+template <bool NEXT>
 __global__ void __launch_bounds__(AS_BLOCK) adam_sh_factored_kernel(AdamShParams a) {
     __shared__ float tile[AS_BLOCK / 64][64 * AS_ROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -212,21 +223,67 @@ __global__ void __launch_bounds__(AS_BLOCK) adam_sh_factored_kernel(AdamShParams
 
     const int rest_f = (a.M - 1) * 3;
     if (rest_f > 0)
-        adam_sh_segment(wl, 3, rest_f, a.p_rest, a.m_rest, a.v_rest, (long long)wave_first * rest_f, n_here * rest_f,
-                        a.ss_rest, a.ib_rest, a, lane);
-    adam_sh_segment(wl, 0, 3, a.p_dc, a.m_dc, a.v_dc, (long long)wave_first * 3, n_here * 3, a.ss_dc, a.ib_dc, a, lane);
+        adam_sh_segment<NEXT>(wl, 3, rest_f, a.p_rest, a.m_rest, a.v_rest, (long long)wave_first * rest_f, n_here * rest_f,
+                              a.ss_rest, a.ib_rest, a, lane);
+    adam_sh_segment<NEXT>(wl, 0, 3, a.p_dc, a.m_dc, a.v_dc, (long long)wave_first * 3, n_here * 3, a.ss_dc, a.ib_dc, a, lane);
+    if (!NEXT) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n_here) {
+        const int idx = wave_first + lane;
+        const float ox = a.xyz_next[3 * (size_t)idx + 0] - a.campos_next[0];
+        const float oy = a.xyz_next[3 * (size_t)idx + 1] - a.campos_next[1];
+        const float oz = a.xyz_next[3 * (size_t)idx + 2] - a.campos_next[2];
+        const float il = 1.0f / sqrtf(ox * ox + oy * oy + oz * oz);
+        float basis[16], dbx[16], dby[16], dbz[16];
+        sh_basis16_grad(a.deg_next, ox * il, oy * il, oz * il, basis, dbx, dby, dbz);
+        const float* sh = wl + lane * AS_ROW;          // [k][c] of this Gaussian, k < M
+        float rgb[3] = {0.f, 0.f, 0.f}, J[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) J[q] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k < a.M) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float v = sh[3 * k + c];
+                    rgb[c] = fmaf(basis[k], v, rgb[c]);
+                    J[3 * c + 0] = fmaf(dbx[k], v, J[3 * c + 0]);
+                    J[3 * c + 1] = fmaf(dby[k], v, J[3 * c + 1]);
+                    J[3 * c + 2] = fmaf(dbz[k], v, J[3 * c + 2]);
+                }
+            }
+        }
+        uint32_t clamp_bits = 0;
+        float* out_rgb = a.cache + 3 * (size_t)idx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float t = rgb[c] + 0.5f;
+            if (t < 0.0f) clamp_bits |= (1u << c);
+            out_rgb[c] = fmaxf(t, 0.0f);
+        }
+        reinterpret_cast<uint32_t*>(a.cache)[3 * (size_t)a.n_total + idx] = clamp_bits;
+        float* out_j = a.cache + 4 * (size_t)a.n_total + 9 * (size_t)idx;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) out_j[q] = J[q];
+    }
 }
 
-extern "C" int32_t gsr_adam_sh_factored(int32_t first, int32_t count, int32_t sh_coeffs, int32_t sh_degree, const float* xyz,
-                                        int32_t n_views, const float* color_grad, int64_t view_stride, const float* campos,
-                                        int32_t campos_stride, float grad_scale,
-                                        float* p_dc, float* m_dc, float* v_dc, float step_size_dc, float inv_bc2_sqrt_dc,
-                                        float* p_rest, float* m_rest, float* v_rest, float step_size_rest,
-                                        float inv_bc2_sqrt_rest, double beta1, double beta2, double eps,
-                                        gsr_stream_t stream_) {
+static int adam_sh_factored_impl(int32_t first, int32_t count, int32_t sh_coeffs, int32_t sh_degree, const float* xyz,
+                                 int32_t n_views, const float* color_grad, int64_t view_stride, const float* campos,
+                                 int32_t campos_stride, float grad_scale,
+                                 float* p_dc, float* m_dc, float* v_dc, float step_size_dc, float inv_bc2_sqrt_dc,
+                                 float* p_rest, float* m_rest, float* v_rest, float step_size_rest,
+                                 float inv_bc2_sqrt_rest, double beta1, double beta2, double eps,
+                                 const float* xyz_next, const float* campos_next, int32_t sh_degree_next, int32_t n_total,
+                                 float* color_cache, gsr_stream_t stream_) {
     if (first < 0 || count < 0 || sh_coeffs < 1 || sh_coeffs > 16 || sh_degree < 0 || sh_degree > 3 ||
         n_views < 1 || n_views > AS_MAX_VIEWS || campos_stride < 3 || view_stride < 0) {
         gsr_set_error("adam_sh_factored: bad sizes (coeffs 1..16, degree 0..3, views 1..%d)", AS_MAX_VIEWS);
+        return GSR_E_INVALID;
+    }
+    if (color_cache && (!xyz_next || !campos_next || sh_degree_next < 0 || sh_degree_next > 3 || n_total < first + count)) {
+        gsr_set_error("adam_sh_factored_next: xyz_next / campos_next missing, degree not in 0..3 or n_total too small");
         return GSR_E_INVALID;
     }
     if (count == 0) return GSR_OK;
@@ -241,10 +298,39 @@ extern "C" int32_t gsr_adam_sh_factored(int32_t first, int32_t count, int32_t sh
     a.p_dc = p_dc; a.m_dc = m_dc; a.v_dc = v_dc; a.p_rest = p_rest; a.m_rest = m_rest; a.v_rest = v_rest;
     a.ss_dc = step_size_dc; a.ib_dc = inv_bc2_sqrt_dc; a.ss_rest = step_size_rest; a.ib_rest = inv_bc2_sqrt_rest;
     a.beta2 = (float)beta2; a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps;
+    a.xyz_next = xyz_next; a.campos_next = campos_next; a.deg_next = sh_degree_next; a.n_total = n_total; a.cache = color_cache;
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GsrProfileScope prof(GSR_K_ADAM, s);
     const unsigned blocks = (unsigned)((count + AS_BLOCK - 1) / AS_BLOCK);
-    hipLaunchKernelGGL(adam_sh_factored_kernel, dim3(blocks), dim3(AS_BLOCK), 0, s, a);
+    if (color_cache) hipLaunchKernelGGL(adam_sh_factored_kernel<true>, dim3(blocks), dim3(AS_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(adam_sh_factored_kernel<false>, dim3(blocks), dim3(AS_BLOCK), 0, s, a);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
+}
+
+extern "C" int32_t gsr_adam_sh_factored(int32_t first, int32_t count, int32_t sh_coeffs, int32_t sh_degree, const float* xyz,
+                                        int32_t n_views, const float* color_grad, int64_t view_stride, const float* campos,
+                                        int32_t campos_stride, float grad_scale,
+                                        float* p_dc, float* m_dc, float* v_dc, float step_size_dc, float inv_bc2_sqrt_dc,
+                                        float* p_rest, float* m_rest, float* v_rest, float step_size_rest,
+                                        float inv_bc2_sqrt_rest, double beta1, double beta2, double eps,
+                                        gsr_stream_t stream_) {
+    return adam_sh_factored_impl(first, count, sh_coeffs, sh_degree, xyz, n_views, color_grad, view_stride, campos, campos_stride,
+                                 grad_scale, p_dc, m_dc, v_dc, step_size_dc, inv_bc2_sqrt_dc, p_rest, m_rest, v_rest,
+                                 step_size_rest, inv_bc2_sqrt_rest, beta1, beta2, eps, nullptr, nullptr, 0, 0, nullptr, stream_);
+}
+
+extern "C" int32_t gsr_adam_sh_factored_next(int32_t first, int32_t count, int32_t sh_coeffs, int32_t sh_degree, const float* xyz,
+                                             int32_t n_views, const float* color_grad, int64_t view_stride, const float* campos,
+                                             int32_t campos_stride, float grad_scale,
+                                             float* p_dc, float* m_dc, float* v_dc, float step_size_dc, float inv_bc2_sqrt_dc,
+                                             float* p_rest, float* m_rest, float* v_rest, float step_size_rest,
+                                             float inv_bc2_sqrt_rest, double beta1, double beta2, double eps,
+                                             const float* xyz_next, const float* campos_next, int32_t sh_degree_next,
+                                             int32_t n_total, float* color_cache, gsr_stream_t stream_) {
+    if (!color_cache) { gsr_set_error("adam_sh_factored_next: color_cache missing"); return GSR_E_INVALID; }
+    return adam_sh_factored_impl(first, count, sh_coeffs, sh_degree, xyz, n_views, color_grad, view_stride, campos, campos_stride,
+                                 grad_scale, p_dc, m_dc, v_dc, step_size_dc, inv_bc2_sqrt_dc, p_rest, m_rest, v_rest,
+                                 step_size_rest, inv_bc2_sqrt_rest, beta1, beta2, eps, xyz_next, campos_next, sh_degree_next,
+                                 n_total, color_cache, stream_);
 }

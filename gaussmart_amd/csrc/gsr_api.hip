@@ -113,7 +113,13 @@ static int validate(const GsrView* v, const GsrGaussians* g) {
             return GSR_E_INVALID;
         }
     }
-    if ((g->shs == nullptr) == (g->colors_precomp == nullptr)) {
+    const bool color_cached = (v->flags & (uint32_t)GSR_FLAG_COLOR_CACHED) != 0;
+    if (color_cached) {   // SH coefficients AND their cached colour for this view (gsr_adam_sh_factored_next)
+        if (!g->shs || !g->colors_precomp || v->channels != 3 || v->sh_coeffs > 16) {
+            gsr_set_error("GSR_FLAG_COLOR_CACHED needs shs (<= 16 coefficients), the colour cache in colors_precomp and 3 channels");
+            return GSR_E_INVALID;
+        }
+    } else if ((g->shs == nullptr) == (g->colors_precomp == nullptr)) {
         gsr_set_error("Please provide excatly one of either SHs or precomputed colors!");
         return GSR_E_INVALID;
     }
@@ -337,7 +343,8 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     if (!grads || !alloc || !geom || !binning || !image || !dL_dcolor || !dL_dallmap || num_rendered < 0 ||
         (g->count > 0 && (!radii || !grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacity)) ||
         (g->shs && !factored && !grads->dL_dshs) || (g->shs_rest && !factored && !grads->dL_dshs_rest) ||
-        (factored && !grads->dL_dcolors) || (g->colors_precomp && !grads->dL_dcolors) ||
+        (factored && !grads->dL_dcolors) ||
+        (g->colors_precomp && !(view->flags & (uint32_t)GSR_FLAG_COLOR_CACHED) && !grads->dL_dcolors) ||
         (g->scales && (!grads->dL_dscales || !grads->dL_drotations)) ||
         (g->transmat_precomp && !grads->dL_dtransmat)) {
         gsr_set_error("backward inputs / gradient outputs missing");
@@ -414,7 +421,7 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     GsrGrads o = *grads;
     if (!g->shs) o.dL_dshs = nullptr;
     if (!g->shs_rest) o.dL_dshs_rest = nullptr;
-    if (!g->colors_precomp && !factored) o.dL_dcolors = nullptr;
+    if ((!g->colors_precomp || (view->flags & (uint32_t)GSR_FLAG_COLOR_CACHED)) && !factored) o.dL_dcolors = nullptr;
     if (factored) { o.dL_dshs = nullptr; o.dL_dshs_rest = nullptr; }
     if (!g->scales) { o.dL_dscales = nullptr; o.dL_drotations = nullptr; }
     if (!g->transmat_precomp) o.dL_dtransmat = nullptr;
@@ -431,8 +438,9 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
         }
         o.dL_dcolors = nullptr;
     }
+    const bool color_cached = (view->flags & (uint32_t)GSR_FLAG_COLOR_CACHED) != 0;
     return gsr_launch_preprocess_bwd(*view, *g, radii, at<float>(geom, GL.splat), at<uint32_t>(geom, GL.clamped),
-                                     row_sums, at<float>(geom, GL.color_jac), o, s);
+                                     row_sums, color_cached ? g->colors_precomp + 4 * (size_t)N : at<float>(geom, GL.color_jac), o, s);
 }
 
 // ------------------------------------------------------------------------------- introspection

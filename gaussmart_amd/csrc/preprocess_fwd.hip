@@ -367,20 +367,40 @@ static void fill_pre_params(PreParams& p, const GsrView& v, const GsrGaussians& 
     p.deg = v.sh_degree; p.M = v.sh_coeffs; p.mod = v.scale_modifier;
     p.view = v.viewmatrix; p.proj = v.projmatrix; p.campos = v.campos;
     p.raw = (v.flags & (uint32_t)GSR_FLAG_RAW_PARAMS) != 0;
-    p.means = g.means3D; p.shs = g.shs; p.shs_rest = g.shs_rest; p.colors = v.channels == 3 ? g.colors_precomp : nullptr /* wide payloads are read by id in K6/K7 */; p.opac = g.opacities;
+    p.means = g.means3D; p.shs = g.shs; p.shs_rest = g.shs_rest; p.colors = (v.channels == 3 && !(v.flags & (uint32_t)GSR_FLAG_COLOR_CACHED)) ? g.colors_precomp : nullptr /* wide payloads are read by id in K6/K7; a colour cache is applied where the colour pass would run */; p.opac = g.opacities;
     p.scales = g.scales; p.rots = g.rotations; p.tprecomp = g.transmat_precomp;
     p.splat = splat; p.clamped = clamped; p.tiles = tiles_touched; p.rect = tile_rect; p.dkey = depth_key; p.radii = radii;
     p.jac = nullptr;
 }
 
 bool gsr_color_jac_available(const GsrView& v, const GsrGaussians& g) {
-    // only the 16-lane register form of the colour pass computes it
+    // only the 16-lane register form of the colour pass computes it (a colour cache always carries it)
+    if (v.flags & (uint32_t)GSR_FLAG_COLOR_CACHED) return true;
     return g.shs != nullptr && v.sh_coeffs <= 16 && !getenv("GSR_COLOR_STAGED");
+}
+
+// GSR_FLAG_COLOR_CACHED: the colour of this view was computed by gsr_adam_sh_factored_next while it updated the
+// coefficients; copy rgb and clamp bits of the visible Gaussians into their records (16 B read + 16 B written each).
+__global__ void __launch_bounds__(PRE_BLOCK) color_apply_kernel(int N, const int32_t* __restrict__ radii,
+                                                                const float* __restrict__ cache, float* __restrict__ splat,
+                                                                uint32_t* __restrict__ clamped) {
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    if (idx >= N || radii[idx] <= 0) return;
+    float* rec = splat + (size_t)idx * GSR_SPLAT_FLOATS;
+    rec[GSR_SP_RGB] = cache[3 * (size_t)idx]; rec[GSR_SP_RGB + 1] = cache[3 * (size_t)idx + 1]; rec[GSR_SP_RGB + 2] = cache[3 * (size_t)idx + 2];
+    clamped[idx] = reinterpret_cast<const uint32_t*>(cache)[3 * (size_t)N + idx];
 }
 
 int gsr_launch_preprocess_color(const GsrView& v, const GsrGaussians& g, float* splat, uint32_t* clamped,
                                 int32_t* radii, float* color_jac, hipStream_t s) {
     if (g.count <= 0 || g.shs == nullptr) return GSR_OK;
+    if (v.flags & (uint32_t)GSR_FLAG_COLOR_CACHED) {
+        GsrProfileScope prof(GSR_K_PREPROCESS_FWD, s);
+        hipLaunchKernelGGL(color_apply_kernel, dim3((g.count + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, s, g.count, radii,
+                           g.colors_precomp, splat, clamped);
+        GSR_LAUNCH_CHECK();
+        return GSR_OK;
+    }
     PreParams p;
     fill_pre_params(p, v, g, splat, clamped, nullptr, nullptr, nullptr, radii);
     p.jac = gsr_color_jac_available(v, g) ? color_jac : nullptr;

@@ -16,6 +16,14 @@ class FusedAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
         self.pending_sh = None      # (features_dc, features_rest, rasterizer.ColorGradRecord) of the last factored backward
+        # Colour cache (gsr_adam_sh_factored_next): while the factored SH step has a Gaussian's new coefficients on chip it can
+        # also evaluate the SH colour of the NEXT view -- the next forward then skips the colour pass and its 192-byte read
+        # per Gaussian.  `next_view` = (camera centre tensor [3] on the device, active SH degree) of that view, set by the
+        # trainer; `color_cache` = (key, tensor f32[13 N]) of the last such step, looked up by render().
+        self.next_view = None
+        self.color_cache = None
+        self._cache_buf = None
+        self._xyz_old = None
 
     # ---- factored SH gradient: the two feature parameters have NO .grad after such a backward; their gradient is the
     # record parked here, which the next full step() turns into an update (so `optimizer.step()` keeps meaning "apply
@@ -40,6 +48,22 @@ class FusedAdam(torch.optim.Adam):
         self.pending_sh = None
         return super().zero_grad(set_to_none=set_to_none)
 
+    @staticmethod
+    def color_cache_key(campos, sh_degree, xyz, f_dc, f_rest):
+        """What a colour cache is valid for: the view (its camera-centre tensor), the active degree and the exact parameter
+        tensors in their current state.  torch's version counters catch every in-place modification made through torch;
+        the optimiser's own kernels write through raw pointers BEFORE the cache is built, so they do not disturb it."""
+        return (campos.data_ptr(), int(sh_degree), int(xyz.shape[0]), xyz.data_ptr(), f_dc.data_ptr(), f_rest.data_ptr(),
+                xyz._version, f_dc._version, f_rest._version, campos._version)
+
+    def lookup_color_cache(self, campos, sh_degree, xyz, f_dc, f_rest):
+        """The cache tensor if the last factored step prepared the colour of exactly this view for exactly these
+        parameters, else None (the forward then runs its ordinary SH colour pass)."""
+        cc = self.color_cache
+        if cc is None or cc[0] != self.color_cache_key(campos, sh_degree, xyz, f_dc, f_rest):
+            return None
+        return cc[1]
+
     @torch.no_grad()
     def step(self, closure=None, only=None, stream=None):
         """`only`: iterable of parameters to update (the others keep their state and step count untouched);
@@ -51,12 +75,19 @@ class FusedAdam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
+        sh_after = None
         if only is None:
             pend = self.take_pending_sh()
-            if pend is not None:        # first: it reads the positions the backward saw, which the launch below updates
+            if pend is not None:
                 f_dc, f_rest, rec = pend
-                self.step_sh_factored(f_dc, f_rest, rec.xyz, rec.gathered if rec.gathered is not None else rec.record,
-                                      rec.n_views, rec.record.numel(), rec.sh_degree, rec.grad_scale, stream=stream)
+                records = rec.gathered if rec.gathered is not None else rec.record
+                if self.next_view is not None and rec.xyz.grad is not None:
+                    # the SH step will also evaluate the NEXT view's colour, which needs the positions AFTER their own
+                    # update: snapshot the positions the backward saw, update the geometry below, then the SH tensors
+                    sh_after = (f_dc, f_rest, rec, records, self._snapshot_xyz(rec.xyz, stream))
+                else:       # first: it reads the positions the backward saw, which the launch below updates
+                    self.step_sh_factored(f_dc, f_rest, rec.xyz, records, rec.n_views, rec.record.numel(), rec.sh_degree,
+                                          rec.grad_scale, stream=stream)
         batches = {}
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
@@ -87,7 +118,37 @@ class FusedAdam(torch.optim.Adam):
                         n, arr(0), arr(1), arr(2), arr(3), (C.c_int64 * n)(*[c[0].numel() for c in chunk]),
                         (C.c_float * n)(*[c[4] for c in chunk]), (C.c_float * n)(*[c[5] for c in chunk]),
                         beta1, beta2, eps, C.c_void_p(stream_h)))
+        if sh_after is not None:
+            f_dc, f_rest, rec, records, xyz_old = sh_after
+            self.step_sh_factored(f_dc, f_rest, xyz_old, records, rec.n_views, rec.record.numel(), rec.sh_degree,
+                                  rec.grad_scale, stream=stream, next_view=self.next_view, xyz_next=rec.xyz)
         return loss
+
+    @torch.no_grad()
+    def step_with_sh(self, f_dc, f_rest, rec, records, n_views, grad_scale=1.0):
+        """Full optimiser step of an iteration whose SH gradient is the factored record `rec` (already taken out of the
+        pending slot): geometry tensors by their .grad, SH tensors from `records`.  Without a next view the SH step runs
+        first (it reads the positions the backward saw, which the geometry step moves); with one (self.next_view) the
+        order is snapshot -> geometry -> SH + colour of the next view from the NEW positions."""
+        stride, deg = rec.record.numel(), rec.sh_degree
+        if self.next_view is not None and rec.xyz.grad is not None:
+            xyz_old = self._snapshot_xyz(rec.xyz)
+            self.step()
+            self.step_sh_factored(f_dc, f_rest, xyz_old, records, n_views, stride, deg, grad_scale,
+                                  next_view=self.next_view, xyz_next=rec.xyz)
+        else:
+            self.step_sh_factored(f_dc, f_rest, rec.xyz, records, n_views, stride, deg, grad_scale)
+            self.step()
+
+    def _snapshot_xyz(self, xyz, stream=None):
+        if self._xyz_old is None or self._xyz_old.shape != xyz.shape or self._xyz_old.device != xyz.device:
+            self._xyz_old = torch.empty_like(xyz)
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                self._xyz_old.copy_(xyz)
+        else:
+            self._xyz_old.copy_(xyz)
+        return self._xyz_old
 
     @torch.no_grad()
     def step_slice(self, p, start, stop, stream=None, count_step=True):
@@ -128,7 +189,7 @@ class FusedAdam(torch.optim.Adam):
 
     @torch.no_grad()
     def step_sh_factored(self, f_dc, f_rest, xyz, records, n_views, view_stride, sh_degree, grad_scale=1.0,
-                         first=0, count=None, stream=None, count_step=True):
+                         first=0, count=None, stream=None, count_step=True, next_view=None, xyz_next=None):
         """Adam update of the two SH parameters from FACTORED gradients (include/gsr.h: gsr_adam_sh_factored):
         `records` holds n_views blocks of `view_stride` floats, each the [N,3] clamp-masked colour gradient of one view
         followed by that view's camera position (rasterizer.ColorGradRecord.record, or the all-gather of it over the
@@ -159,9 +220,28 @@ class FusedAdam(torch.optim.Adam):
             raise _lib.GsrError("step_sh_factored: f_dc and f_rest must share betas and eps")
         (beta1, beta2, eps) = sizes[0]
         M = 1 + f_rest.shape[1]
+        want_next = next_view is not None and xyz_next is not None and first == 0 and count == N and M >= 1
+        if want_next:
+            campos_next, deg_next = next_view
+            if (not campos_next.is_cuda or campos_next.dtype != torch.float32 or campos_next.numel() != 3
+                    or not campos_next.is_contiguous() or xyz_next.shape[0] != N or not xyz_next.is_contiguous()):
+                want_next = False
         with torch.cuda.device(f_dc.device):
             stream_h = (stream if stream is not None else torch.cuda.current_stream(f_dc.device)).cuda_stream
             a, b = ptrs
+            if want_next:
+                if self._cache_buf is None or self._cache_buf.numel() != 13 * N or self._cache_buf.device != f_dc.device:
+                    self._cache_buf = torch.empty(13 * N, dtype=torch.float32, device=f_dc.device)
+                _lib.check(L.gsr_adam_sh_factored_next(
+                    int(first), int(count), M, int(sh_degree), C.c_void_p(xyz.data_ptr()), int(n_views),
+                    C.c_void_p(records.data_ptr()), int(view_stride), C.c_void_p(records.data_ptr() + 12 * N), int(view_stride),
+                    float(grad_scale),
+                    C.c_void_p(a[0].data_ptr()), C.c_void_p(a[1].data_ptr()), C.c_void_p(a[2].data_ptr()), a[3], a[4],
+                    C.c_void_p(b[0].data_ptr()), C.c_void_p(b[1].data_ptr()), C.c_void_p(b[2].data_ptr()), b[3], b[4],
+                    beta1, beta2, eps, C.c_void_p(xyz_next.data_ptr()), C.c_void_p(campos_next.data_ptr()), int(deg_next), int(N),
+                    C.c_void_p(self._cache_buf.data_ptr()), C.c_void_p(stream_h)))
+                self.color_cache = (self.color_cache_key(campos_next, deg_next, xyz_next, f_dc, f_rest), self._cache_buf)
+                return
             _lib.check(L.gsr_adam_sh_factored(
                 int(first), int(count), M, int(sh_degree), C.c_void_p(xyz.data_ptr()), int(n_views),
                 C.c_void_p(records.data_ptr()), int(view_stride), C.c_void_p(records.data_ptr() + 12 * N), int(view_stride),

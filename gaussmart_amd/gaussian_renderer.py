@@ -156,9 +156,16 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
     if raw:
         # same kernels, activations + dc|rest concatenation fused inside (rasterizer.py: _RasterizeGaussiansRaw)
+        factored = factored_sh_grad and pc._features_rest.shape[1] > 0
+        # the optimiser step may have left the SH colour of exactly this view for exactly these parameters
+        # (FusedAdam.color_cache, gsr_adam_sh_factored_next): then the forward skips its SH colour pass
+        cache = None
+        lookup = getattr(getattr(pc, "optimizer", None), "lookup_color_cache", None)
+        if factored and lookup is not None and torch.is_grad_enabled():
+            cache = lookup(viewpoint_camera.camera_center, pc.active_sh_degree, pc._xyz, pc._features_dc, pc._features_rest)
         rendered_image, radii, allmap = rasterize_gaussians_raw(
             xyz, means2D, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation, raster_settings,
-            factored_sh_grad=factored_sh_grad and pc._features_rest.shape[1] > 0)
+            factored_sh_grad=factored, color_cache=cache)
     else:
         rendered_image, radii, allmap = rasterizer(
             means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,

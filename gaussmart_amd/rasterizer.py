@@ -421,7 +421,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
     element-wise launches and two 192 MB copies per iteration; results equal the activated path."""
 
     @staticmethod
-    def forward(ctx, xyz, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings, flags):
+    def forward(ctx, xyz, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings, flags,
+                color_cache=None):
         L = _lib.lib()
         device = xyz.device
         if device.type != "cuda":
@@ -436,6 +437,10 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             raise ValueError("features_dc must be [N,1,3] and features_rest [N,K-1,3]")
         M = 1 + f_rest.shape[1]
         flags = int(flags) | _lib.GSR_FLAG_RAW_PARAMS
+        if color_cache is not None:       # the SH colour of this view was left by the optimiser step (FusedAdam.color_cache)
+            if color_cache.numel() != 13 * N or color_cache.dtype != torch.float32 or color_cache.device != device:
+                raise ValueError("color_cache must be float32 [13 N] on the parameters' device")
+            flags |= _lib.GSR_FLAG_COLOR_CACHED
         pending = _pop_pending(device, xyz)
         hook = color_stream = None
         if pending is not None:
@@ -447,7 +452,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         rest = f_rest if f_rest.shape[1] > 0 else None
         with torch.cuda.device(device):
             view, keep = _make_view(rs, M, flags, device)
-            g = _lib.GsrGaussians(N, _ptr(xyz), _ptr(f_dc), None, _ptr(opacity_raw), _ptr(scaling_raw),
+            g = _lib.GsrGaussians(N, _ptr(xyz), _ptr(f_dc), _ptr(color_cache), _ptr(opacity_raw), _ptr(scaling_raw),
                                   _ptr(rotation_raw), None, _ptr(rest) if rest is not None else None)
             color = torch.empty((3, H, W), dtype=torch.float32, device=device)
             allmap = torch.empty((7, H, W), dtype=torch.float32, device=device)
@@ -465,6 +470,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         ctx.lease = alloc.kept
         ctx.raster_settings, ctx.flags, ctx.num_rendered, ctx.M = rs, flags & ~_lib.GSR_FLAG_DEFER_COLOR, int(out.num_rendered), M
         ctx.view_keep = keep
+        ctx.color_cache = color_cache        # (the backward reads d(rgb)/d(dir) from it)
         ctx.set_materialize_grads(False)     # no zero tensors for the unused radii / image gradients
         ctx.save_for_backward(xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, radii,
                               alloc.buffers[_lib.GSR_BUF_GEOM], alloc.buffers[_lib.GSR_BUF_BINNING],
@@ -487,7 +493,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         rest = f_rest if f_rest.shape[1] > 0 else None
         with torch.cuda.device(device):
             view, keep = _make_view(rs, ctx.M, ctx.flags, device, 3, ctx.view_keep)
-            g = _lib.GsrGaussians(N, _ptr(xyz), _ptr(f_dc), None, _ptr(opacity_raw), _ptr(scaling_raw),
+            g = _lib.GsrGaussians(N, _ptr(xyz), _ptr(f_dc), _ptr(ctx.color_cache), _ptr(opacity_raw), _ptr(scaling_raw),
                                   _ptr(rotation_raw), None, _ptr(rest) if rest is not None else None)
             # ONE buffer for the six parameter gradients, [xyz | f_dc | opacity | scaling | rotation | f_rest]: the
             # data-parallel step all-reduces it as a whole (or as "geometry + dc" / "rest" halves) without copies
@@ -527,7 +533,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         if factored:
             _COLOR_GRAD[(torch.device(device), _model_key(xyz))] = ColorGradRecord(flat, flat[:n_head], record, N, ctx.M,
                                                                                    rs.sh_degree, xyz)
-        return d_xyz, d_2d, d_dc, d_rest, d_op, d_sc, d_rot, None, None
+        return d_xyz, d_2d, d_dc, d_rest, d_op, d_sc, d_rot, None, None, None
 
 
 def _wants_grad(*tensors):
@@ -563,7 +569,7 @@ def _forward_only(device, rs, flags, sh_coeffs, gaussians_args, N):
 
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
-                            raster_settings, flags=None, factored_sh_grad=False):
+                            raster_settings, flags=None, factored_sh_grad=False, color_cache=None):
     """(color, radii, allmap) from the model's raw parameter tensors; activations fused in-kernel.
     `factored_sh_grad`: the backward leaves NO gradient on features_dc / features_rest; it parks a ColorGradRecord
     (take_color_grad) for FusedAdam.step_sh_factored instead -- only for callers that own the optimiser step."""
@@ -581,7 +587,7 @@ def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_ra
     if factored_sh_grad:
         flags |= _lib.GSR_FLAG_FACTORED_SH_GRAD
     return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
-                                        rotation_raw, raster_settings, flags)
+                                        rotation_raw, raster_settings, flags, color_cache if factored_sh_grad else None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,

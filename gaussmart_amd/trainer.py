@@ -82,14 +82,19 @@ def optimizer_step(gaussians, view_parallel: ViewParallel = None):
 
 
 def training_step(gaussians, viewpoint_cam, gt_image, opt, pipe, background, iteration,
-                  view_parallel: ViewParallel = None, render_fn=render, step_optimizer=True):
+                  view_parallel: ViewParallel = None, render_fn=render, step_optimizer=True, next_cam=None):
     """forward + loss + backward (+ gradient exchange) (+ Adam).  Returns (render_pkg, losses);
     nothing is synchronised with the host.  With `step_optimizer=False` the gradients are exchanged here (view-parallel
     runs) and the caller finishes the iteration with optimizer_step(gaussians) or gaussians.optimizer.step() -- train()
-    does, after the densification bookkeeping."""
+    does, after the densification bookkeeping.
+    `next_cam`: the view the NEXT iteration will render, if the caller knows it: the factored SH optimiser step then also
+    leaves that view's SH colours (it has the new coefficients on chip anyway) and the next forward skips its colour pass."""
     gaussians.update_learning_rate(iteration)
     on_device = gaussians.get_xyz.is_cuda
     factored = _use_factored_sh_grad(gaussians, pipe, render_fn, on_device)
+    if isinstance(getattr(gaussians, "optimizer", None), FusedAdam):
+        gaussians.optimizer.next_view = (next_cam.camera_center, gaussians.active_sh_degree) \
+            if (factored and next_cam is not None and getattr(pipe, "color_cache", True)) else None
     if factored:
         render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=False, factored_sh_grad=True)
     else:

@@ -231,14 +231,12 @@ class ViewParallel:
         stride, deg = rec.record.numel(), rec.sh_degree
         active = self.world_size > 1 or self.force          # ranks to exchange with
         if not active and not (self.overlap_local and self.pipelined and rec.head.is_cuda):
-            optimizer.step_sh_factored(f_dc, f_rest, rec.xyz, rec.record, 1, stride, deg)
-            optimizer.step()
+            optimizer.step_with_sh(f_dc, f_rest, rec, rec.record, 1)
             return
         self.finish()                                     # the previous step's SH update (normally long done)
         if active and not (self.pipelined and rec.head.is_cuda and dist.get_backend(self.pg) == "nccl"):
             self.exchange_factored(rec)
-            optimizer.step_sh_factored(f_dc, f_rest, rec.xyz, rec.gathered, rec.n_views, stride, deg, rec.grad_scale)
-            optimizer.step()                              # features have no .grad: skipped there
+            optimizer.step_with_sh(f_dc, f_rest, rec, rec.gathered, rec.n_views, rec.grad_scale)
             return
         # Pipelined: the main stream waits only for the 40 MB geometry all-reduce, updates xyz / opacity / scaling /
         # rotation and starts the next forward; the all-gather of the colour gradients and the SH update run on the
@@ -264,14 +262,22 @@ class ViewParallel:
             self._wait_on_main(w_head, dev)               # current stream waits for the geometry collective only
         if self._side is None:
             self._side = torch.cuda.Stream(device=dev)
+        next_view = getattr(optimizer, "next_view", None)
+        optimizer.step()                                  # geometry tensors (the features have no .grad: skipped)
+        geo_done = None
+        if next_view is not None:                         # the SH step also evaluates the next view's colour from the NEW
+            geo_done = torch.cuda.Event()                 # positions: it has to run behind the geometry step
+            geo_done.record(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self._side):
             self._side.wait_event(snapped)
+            if geo_done is not None:
+                self._side.wait_event(geo_done)
             if w_rec is not None:
                 w_rec.wait()
-            optimizer.step_sh_factored(f_dc, f_rest, self._xyz_snap, records, n_views, stride, deg, scale, stream=self._side)
+            optimizer.step_sh_factored(f_dc, f_rest, self._xyz_snap, records, n_views, stride, deg, scale, stream=self._side,
+                                       next_view=next_view, xyz_next=rec.xyz if next_view is not None else None)
             ev = torch.cuda.Event()
             ev.record(self._side)
-        optimizer.step()                                  # features have no .grad: skipped
         rec.flat.record_stream(self._side)
         self._pending = ev
         rasterizer.set_pending_param_event(dev, ev, self._side, model=self.g._xyz)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 3
+#define GSR_ABI_VERSION 4
 #define GSR_MAX_CHANNELS 64   /* widest per-pixel payload of gsr_forward / gsr_backward */
 
 typedef void* gsr_stream_t; /* hipStream_t */
@@ -69,6 +69,13 @@ enum {
                                        nothing is kept for a backward -- the IMAGE buffer is not requested (out->image =
                                        NULL), the touch words of BINNING are not written and gsr_backward must not be
                                        called with these buffers.  Honoured for 3-channel output; ignored for wide payloads */
+    GSR_FLAG_COLOR_CACHED = 256,    /* `shs` AND `colors_precomp` given, channels = 3: colors_precomp is a COLOUR CACHE, f32[13 N] =
+                                       [ rgb [N,3] | clamp bits u32 [N] | d(rgb)/d(dir) [N,9] ], holding the SH colour of THIS view
+                                       for THESE coefficients and positions as gsr_adam_sh_factored_next left it.  gsr_forward
+                                       copies rgb / clamp bits of the visible Gaussians into its records where the SH colour
+                                       pass would run (same position in the stream, same GSR_FLAG_DEFER_COLOR handling) and
+                                       never reads the coefficients; gsr_backward (pass the same pointer and flag) takes
+                                       d(rgb)/d(dir) from the cache.  The caller guarantees that the cache matches */
     GSR_FLAG_FACTORED_SH_GRAD = 32  /* gsr_backward with `shs`: the SH gradient of one view is the outer product
                                        basis_k(dir) x g_c of the 16 basis values of the view direction and the
                                        clamp-masked colour gradient g = dL/drgb (utils/sh_utils.py:57-112 is linear in
@@ -256,6 +263,20 @@ int32_t gsr_adam_sh_factored(int32_t first, int32_t count, int32_t sh_coeffs, in
                              float* p_dc, float* m_dc, float* v_dc, float step_size_dc, float inv_bc2_sqrt_dc,
                              float* p_rest, float* m_rest, float* v_rest, float step_size_rest, float inv_bc2_sqrt_rest,
                              double beta1, double beta2, double eps, gsr_stream_t stream);
+
+/* The same step, followed -- for the same Gaussians, from the coefficients just written, still on chip -- by the SH colour of
+ * the NEXT view: color_cache f32[13 n_total] = [ rgb [n_total,3] (+0.5, clamped at 0) | clamp bits u32 [n_total] |
+ * d(rgb)/d(dir) [n_total,9] ] for camera position campos_next (device f32[3]), positions xyz_next (device [n_total,3]: the
+ * positions the next forward will see, i.e. AFTER their own optimiser step) and active degree sh_degree_next.  A forward /
+ * backward with GSR_FLAG_COLOR_CACHED then skips the SH colour pass and its 192-byte read per Gaussian altogether. */
+int32_t gsr_adam_sh_factored_next(int32_t first, int32_t count, int32_t sh_coeffs, int32_t sh_degree, const float* xyz,
+                                  int32_t n_views, const float* color_grad, int64_t view_stride, const float* campos,
+                                  int32_t campos_stride, float grad_scale,
+                                  float* p_dc, float* m_dc, float* v_dc, float step_size_dc, float inv_bc2_sqrt_dc,
+                                  float* p_rest, float* m_rest, float* v_rest, float step_size_rest, float inv_bc2_sqrt_rest,
+                                  double beta1, double beta2, double eps,
+                                  const float* xyz_next, const float* campos_next, int32_t sh_degree_next, int32_t n_total,
+                                  float* color_cache, gsr_stream_t stream);
 
 /* Row compaction of the per-Gaussian tensors (pruning, scene/gaussian_model.py:398-470: `tensor[mask]` for the six
  * parameters, their Adam moments and the densification statistics).  Two calls:
