@@ -146,6 +146,14 @@ class TrainState:
         self.seed = seed
         self.rng = random.Random(seed)
         self.stack, self.epoch = None, 0
+        self.next_cam = None        # the view of the next iteration, drawn one iteration ahead (see train())
+
+    def draw(self, cameras, view_parallel=None):
+        """Next view of the schedule: epochs are shuffled stacks popped at random (train.py:99-102)."""
+        if not self.stack:
+            self.stack = list(view_parallel.shard_views(cameras, self.seed + self.epoch)) if view_parallel else list(cameras)
+            self.epoch += 1
+        return self.stack.pop(self.rng.randint(0, len(self.stack) - 1))
 
 
 def train(gaussians, cameras, opt, pipe, background, *, cameras_extent=1.0, first_iter=0, iterations=None,
@@ -163,21 +171,21 @@ def train(gaussians, cameras, opt, pipe, background, *, cameras_extent=1.0, firs
     if final_iteration is None:
         final_iteration = opt.iterations
     st = state if state is not None else TrainState(seed)
-    rng = st.rng
     device = gaussians.get_xyz.device
     t0 = time.time()
     last = None
     for iteration in range(first_iter + 1, iterations + 1):
         if iteration % 1000 == 0:
             gaussians.oneupSHdegree()
-        if not st.stack:
-            st.stack = list(view_parallel.shard_views(cameras, st.seed + st.epoch)) if view_parallel else list(cameras)
-            st.epoch += 1
-        cam = st.stack.pop(rng.randint(0, len(st.stack) - 1))
+        # views are drawn ONE iteration ahead (same sequence, same RNG use): the optimiser step of this iteration can then
+        # leave the SH colours of the next view (training_step(next_cam=...)), which skips that iteration's colour pass
+        cam = st.next_cam if st.next_cam is not None else st.draw(cameras, view_parallel)
+        st.next_cam = st.draw(cameras, view_parallel)
         gt = cam.original_image.to(device)
         # the optimizer step comes after the densification bookkeeping, as in the reference
         render_pkg, last = training_step(gaussians, cam, gt, opt, pipe, background, iteration,
-                                         view_parallel=view_parallel, step_optimizer=False)
+                                         view_parallel=view_parallel, step_optimizer=False,
+                                         next_cam=st.next_cam if iteration < final_iteration else None)
         densification_step(gaussians, render_pkg, opt, iteration, cameras_extent, white_background, view_parallel)
         if iteration < final_iteration:
             optimizer_step(gaussians)      # the exchange of a view-parallel run already happened in training_step

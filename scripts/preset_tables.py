@@ -3,11 +3,11 @@ Usage: python scripts/preset_tables.py profiles/r02_v1_presets"""
 import csv, json, sys
 base = sys.argv[1]
 names = ["headline_r6", "headline_r12", "headline_r24", "scan24", "bicycle", "truck"]
-FWD = ("preprocess_fwd", "preprocess_color", "rs_", "scan_reduce_kernel<unsigned int", "scan_apply_kernel<unsigned int", "emit_instances",
+FWD = ("preprocess_fwd", "preprocess_color", "color_apply", "rs_", "scan_reduce_kernel<unsigned int", "scan_apply_kernel<unsigned int", "emit_instances",
        "rank_gather", "finalize_bins", "render_fwd")
 ADAM = ("adam_",)
 groups = [("K6 render_fwd", ("render_fwd",)), ("K7 render_bwd", ("render_bwd",)), ("reduce_rows", ("reduce_rows",)),
-          ("K8 preprocess_bwd", ("preprocess_bwd",)), ("K1 + colour", ("preprocess_fwd", "preprocess_color")),
+          ("K8 preprocess_bwd", ("preprocess_bwd",)), ("K1 + colour (pass or cache apply)", ("preprocess_fwd", "preprocess_color", "color_apply")),
           ("sorts (18 launches)", ("rs_",)), ("emit + gather + finalize", ("emit_instances", "rank_gather", "finalize_bins")),
           ("slot count + scans", ("slot_count", "scan_")), ("Adam (SH + geometry)", ADAM), ("loss + regularizer", ("loss_", "reg_", "objective"))]
 rows, ktab = [], {}
