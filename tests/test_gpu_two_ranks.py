@@ -41,7 +41,8 @@ def _worker(rank, world, port, out_dir, factored, n=20000, w=320, h=200):
     assert vp.world_size == world
     losses = []
     for i in range(4):
-        _, parts = training_step(m, cam, gt, opt, pipe, bg, 10000 + i, view_parallel=vp)
+        # (the next view is announced: from the second step on the forward takes its SH colours from the optimiser's cache)
+        _, parts = training_step(m, cam, gt, opt, pipe, bg, 10000 + i, view_parallel=vp, next_cam=cam)
         losses.append(float(parts["total"]))
     vp.finish()
     torch.cuda.synchronize()
