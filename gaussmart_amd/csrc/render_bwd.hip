@@ -21,6 +21,7 @@
 //     block's OWN 80-byte sub-row of that instance (16 sub-rows per instance) plus a 1-byte flag;
 //   * reduce_rows adds the flagged sub-rows in fixed order => bitwise reproducible gradients, and
 //     HBM sees plain streaming stores instead of ~18 atomics per pixel-splat pair.
+#include <stdlib.h>
 #include "gsr_common.h"
 #include "pair_eval.h"
 #include "wave_reduce.h"
@@ -82,8 +83,13 @@ __device__ __forceinline__ uint32_t rb_defined_touch(uint32_t word, uint32_t pos
 #define RB_MIN_WAVES 4   // <= 128 VGPRs, no scratch: measured 0.825 ms at 1M/1080p (5 waves spill: 1.13 ms)
 #endif
 // FEAT16: see render_fwd.hip -- 0 = RGB from the record, 1..4 = up to 16*FEAT16 feature channels by id.
-template <int FEAT16>
+// PROBE (developer builds only: make PROBES=1, scripts/dev_probe.py): 1 = eight more dependent VALU per iteration,
+// 4 = eight more dependent SALU, 3 = no row store (WRONG gradients: it exists to time the loop), 6 = 20 KB more LDS per
+// workgroup (four waves per SIMD instead of five).
+template <int FEAT16, int PROBE = 0>
 __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) render_bwd_kernel(RenderBwdParams p) {
+    __shared__ float s_probe_pad[PROBE == 6 ? 5120 : 1];
+    if (PROBE == 6 && p.W < 0) s_probe_pad[threadIdx.x] = 1.f;
     __shared__ float4 s_rec_all[RB_WAVES][64 * 5];
     // wide payload, up to 32 channels: features of the staged entries this quad touched, [entry][channel] (see render_fwd)
     constexpr bool STAGE_FEAT = FEAT16 == 1 || FEAT16 == 2;
@@ -191,11 +197,15 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
 
     while (hi > 0) {
         const int lo = max(0, hi - 64), nb = hi - lo;
-s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_rec[lane * 5 + 3] = pf3; s_rec[lane * 5 + 4] = pf4;
         const uint32_t row_of_lane = pf_row;          // emission index of staged entry `lane`
         const uint32_t touch_of_lane = pf_touch;      // 4 bytes (one per quad) x 4 bits (one per 4x4 block): blended there?
         // first gradient row of staged entry `lane` (its rows are dense, in (quad, block) order of the set bits)
         const uint32_t slot_of_lane = lane < nb ? p.slot_off[row_of_lane] : 0u;
+        // the record's two cull-rect words mean nothing to the backward: the staged copy carries the entry's first row
+        // and its touch word there instead, so a block that picks entry j reads them with the record (they used to come
+        // through two ds_bpermute per iteration)
+        s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_rec[lane * 5 + 3] = pf3;
+        s_rec[lane * 5 + 4] = make_float4(pf4.x, pf4.y, __uint_as_float(slot_of_lane), __uint_as_float(touch_of_lane));
         const uint32_t id_of_lane = ids_cur;          // Gaussian id of staged entry `lane` (wide payload only)
         float4 ft[NQ];
         const bool feat_needed = STAGE_FEAT && lane < nb && ((touch_of_lane >> (8 * wave)) & 0xFu) != 0u;
@@ -238,6 +248,7 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
             m0 = __builtin_bitreverse64(__ballot((t & 1u) != 0)); m1 = __builtin_bitreverse64(__ballot((t & 2u) != 0));
             m2 = __builtin_bitreverse64(__ballot((t & 4u) != 0)); m3 = __builtin_bitreverse64(__ballot((t & 8u) != 0));
         }
+        float probe_v = pxf; uint32_t probe_s = (uint32_t)__builtin_amdgcn_readfirstlane(nb);
         for (;;) {
             // deepest entry of each block's mask first; the four picks reach the lanes packed in one 64-bit scalar
             const int r0_ = rb_take_first(m0), r1_ = rb_take_first(m1), r2_ = rb_take_first(m2), r3_ = rb_take_first(m3);
@@ -254,6 +265,14 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
             // and a lane that does not blend this splat gets alpha = G = 0 and harmless finite geometry, which
             // makes all 18 of its partial derivatives exact zeros and leaves its recursion state untouched
             // (T / (1 - 0) = T; the suffix sums advance by a zero-weight term).
+            if (PROBE == 1) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(probe_v));
+            }
+            if (PROBE == 4) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(probe_s) : : "scc");
+            }
             GsrPair pr;
             const bool ok = gsr_pair_eval(pxf, pyf, a0, a1, a2, a3.z, pr);
             const bool active = has && cidx < last_contributor && ok;
@@ -262,8 +281,10 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
             float gT[9];
             float gxy0, gxy1, gn0, gn1, gn2, gopa, gc0, gc1, gc2;
             float w_pair;   // blending weight of this pair (wide payload: d feature = w * dL/dpixel)
+            uint32_t rec_slot, rec_touch;   // first gradient row and touch word of this row's entry (staged with the record)
             {
                 const float4 a4 = s_rec[j * 5 + 4];
+                rec_slot = __float_as_uint(a4.z); rec_touch = __float_as_uint(a4.w);
                 const float alpha = active ? pr.alpha : 0.f, G = active ? pr.G : 0.f, c_d = active ? pr.depth : 1.f;
                 const float sx = active ? pr.sx : 0.f, sy = active ? pr.sy : 0.f, inv_pz = active ? pr.inv_pz : 0.f;
                 const float one_m_alpha = 1.0f - alpha;
@@ -358,8 +379,7 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
                 const float xy = row_sum2(gxy0, gxy1, l16);
                 // every row whose to-do bit was set writes its slot (zeros if no pixel turned out active), so
                 // the reduction never reads a row that was not written
-                const uint32_t tw = (uint32_t)__shfl((int)touch_of_lane, j, 64);
-                const size_t slot = (size_t)(uint32_t)__shfl((int)slot_of_lane, j, 64) + __popc(tw & below_mask);
+                const size_t slot = (size_t)rec_slot + __popc(rec_touch & below_mask);
                 if (has) {
                     float* row = p.grad_rows + slot * RB_ROW;
                     row[l16 < 9 ? l16 : l16 + 2] = tot;                       // skip the two xy columns
@@ -381,6 +401,8 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
                 }
             }
         }
+        if (PROBE == 1 && probe_v == 1.2345f) T += 1.f;
+        if (PROBE == 4 && probe_s == 0x7fffffffu) T += 1.f;
         __builtin_amdgcn_wave_barrier();   // all reads of this batch precede the next batch's LDS writes
         hi = lo;
     }
@@ -508,7 +530,18 @@ int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32
     p.n_tiles = p.gx * gy; p.per_xcd = (p.n_tiles + 7) / 8;
     const dim3 grid(8 * p.per_xcd), block(RB_BLOCK);
     if (feat == nullptr) {
-        hipLaunchKernelGGL(render_bwd_kernel<0>, grid, block, 0, s, p);
+#ifdef GSR_DEV_PROBES
+        const char* e = getenv("GSR_K7_PROBE");   // re-read per launch
+        switch (e ? atoi(e) : 0) {
+            case 1: hipLaunchKernelGGL((render_bwd_kernel<0, 1>), grid, block, 0, s, p); break;
+            case 3: hipLaunchKernelGGL((render_bwd_kernel<0, 3>), grid, block, 0, s, p); break;
+            case 4: hipLaunchKernelGGL((render_bwd_kernel<0, 4>), grid, block, 0, s, p); break;
+            case 6: hipLaunchKernelGGL((render_bwd_kernel<0, 6>), grid, block, 0, s, p); break;
+            default: hipLaunchKernelGGL((render_bwd_kernel<0>), grid, block, 0, s, p);
+        }
+#else
+        hipLaunchKernelGGL((render_bwd_kernel<0>), grid, block, 0, s, p);
+#endif
     } else {
         switch ((v.channels + 15) / 16) {
             case 1: hipLaunchKernelGGL(render_bwd_kernel<1>, grid, block, 0, s, p); break;
