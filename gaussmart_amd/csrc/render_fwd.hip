@@ -15,6 +15,7 @@
 //   * the wave leaves as soon as ITS 64 pixels are done (quad-level early termination);
 //   * per (instance, quad) it records one byte: "blended into at least one pixel" -- the exact set of
 //     pairs the backward has to evaluate.
+#include <stdlib.h>
 #include "gsr_common.h"
 #include "pair_eval.h"
 
@@ -62,7 +63,10 @@ __device__ __forceinline__ uint32_t row_or_step(uint32_t v) {
 // SAVE = false: forward-only rendering (render.py / view.py under torch.no_grad(); utils/mesh_utils.py:100-123): no
 // touch bytes, no per-pixel state for a backward that will never run -- the mask bookkeeping, four DPP OR steps and
 // eight readlanes per batch and 20 of the 60 bytes written per pixel disappear.
-template <int FEAT16, bool SAVE>
+// PROBE (developer builds only: make PROBES=1, scripts/dev_probe.py): 1 = eight more dependent VALU per splat, 4 = eight
+// more dependent SALU, 2 = no distortion arithmetic, 3 = four LDS reads instead of five, 5 = no reciprocal in the depth
+// mapping.  Probes 2, 3 and 5 render WRONG images: they exist to time the loop (DESIGN.md section 4 holds what they showed).
+template <int FEAT16, bool SAVE, int PROBE = 0>
 __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : 2) render_fwd_kernel(RenderFwdParams p) {
     __shared__ float4 s_rec_all[RF_WAVES][64 * 5];
     // wide payload: the features of the staged entries that survive the cull, [entry][channel], wave-private
@@ -161,29 +165,40 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
             __builtin_amdgcn_wave_barrier();
         }
         uint32_t mine_lo = 0u, mine_hi = 0u;   // staged splats THIS pixel blends (bit j)
+        float probe_v = pxf; uint32_t probe_s = (uint32_t)__builtin_amdgcn_readfirstlane(nb);
         while (m) {
             // every lane is active here (the loop is wave-uniform), so the vote sees the whole wave
             if (__all(done)) break;
             const int j = __builtin_ctzll(m);
             m &= m - 1;
+            if (PROBE == 4) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(probe_s) : : "scc");
+            }
             if (done) continue;
             const uint32_t contributor = (uint32_t)(base + j + 1);   // 1-based position in the tile list
             const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
             const float4 a3 = s_rec[j * 5 + 3];
+            if (PROBE == 1) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(probe_v));
+            }
             GsrPair pr;
             if (!gsr_pair_eval(pxf, pyf, a0, a1, a2, a3.z, pr)) continue;
             const float alpha = pr.alpha, depth = pr.depth;
             const float test_T = T * (1.0f - alpha);
             if (test_T < GSR_T_EPS) { done = true; continue; }
-            const float4 a4 = s_rec[j * 5 + 4];
+            const float4 a4 = PROBE == 3 ? a3 : s_rec[j * 5 + 4];
             const float w = alpha * T;
             const float A = 1.0f - T;
             float dm_dz_unused;
-            const float m_d = gsr_depth_map(depth, dm_dz_unused);
-            dist += (m_d * m_d * A + M2 - 2.0f * m_d * M1) * w;
+            const float m_d = PROBE == 5 ? depth : gsr_depth_map(depth, dm_dz_unused);
+            if (PROBE != 2) {
+                dist += (m_d * m_d * A + M2 - 2.0f * m_d * M1) * w;
+                M1 += m_d * w;
+                M2 += m_d * m_d * w;
+            }
             Dacc += depth * w;
-            M1 += m_d * w;
-            M2 += m_d * m_d * w;
             if (T > 0.5f) { med_depth = depth; med_contrib = contributor; }
             N0 += a2.w * w; N1 += a3.x * w; N2 += a3.y * w;
             if (FEAT16 == 0) {
@@ -207,6 +222,8 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
                 mine_lo |= (uint32_t)bit; mine_hi |= (uint32_t)(bit >> 32);
             }
         }
+        if (PROBE == 1) C0 += probe_v * 1e-30f;
+        if (PROBE == 4) C0 += (float)probe_s * 1e-30f;
         if (!SAVE) {
             __builtin_amdgcn_wave_barrier();   // all reads of this batch precede the next batch's LDS writes
             continue;
@@ -279,7 +296,21 @@ int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float*
     const dim3 grid(8 * p.per_xcd), block(RF_BLOCK);
     if (feat == nullptr) {
         if (v.flags & (uint32_t)GSR_FLAG_FORWARD_ONLY) hipLaunchKernelGGL((render_fwd_kernel<0, false>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((render_fwd_kernel<0, true>), grid, block, 0, s, p);
+        else {
+#ifdef GSR_DEV_PROBES
+            const char* e = getenv("GSR_K6_PROBE");   // re-read per launch
+            switch (e ? atoi(e) : 0) {
+                case 1: hipLaunchKernelGGL((render_fwd_kernel<0, true, 1>), grid, block, 0, s, p); break;
+                case 2: hipLaunchKernelGGL((render_fwd_kernel<0, true, 2>), grid, block, 0, s, p); break;
+                case 3: hipLaunchKernelGGL((render_fwd_kernel<0, true, 3>), grid, block, 0, s, p); break;
+                case 4: hipLaunchKernelGGL((render_fwd_kernel<0, true, 4>), grid, block, 0, s, p); break;
+                case 5: hipLaunchKernelGGL((render_fwd_kernel<0, true, 5>), grid, block, 0, s, p); break;
+                default: hipLaunchKernelGGL((render_fwd_kernel<0, true>), grid, block, 0, s, p);
+            }
+#else
+            hipLaunchKernelGGL((render_fwd_kernel<0, true>), grid, block, 0, s, p);
+#endif
+        }
     } else {
         switch ((v.channels + 15) / 16) {   // (wide payloads always keep the backward state)
             case 1: hipLaunchKernelGGL((render_fwd_kernel<1, true>), grid, block, 0, s, p); break;

@@ -42,7 +42,8 @@ for _ in range(5): step()
 res = {p: [] for p in probes}
 for rnd in range(5):
     for p in probes:
-        os.environ[var] = str(p)
+        if p: os.environ[var] = str(p)
+        else: os.environ.pop(var, None)   # 0 = the product kernel
         for _ in range(2): step()
         _lib.profile_reset(); _lib.profile_enable(big)
         for _ in range(12): step()
