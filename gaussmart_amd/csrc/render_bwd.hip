@@ -181,26 +181,27 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 pf0, pf1, pf2, pf3, pf4;
     uint32_t pf_touch = 0;   // named (not an array): keeps the prefetch in VGPRs, not scratch
-    uint32_t pf_row = 0;
+    uint32_t pf_slot = 0;    // first gradient row of the prefetched entry (slot_off[emission index]: a dependent load, so
+                             // the emission indices run two batches ahead like the ids)
     int hi = max_contrib;
     // ids run two batches ahead of the replay, records (and the per-entry words) one batch ahead
-    uint32_t ids_cur, ids_nxt;
+    uint32_t ids_cur, ids_nxt, rows_nxt;
     {
         const int lo = max(0, hi - 64), cnt = hi - lo;
         ids_cur = lane < cnt ? p.point_list[r0 + lo + lane] : 0u;
         GSR_GATHER5(ids_cur, cnt);
-        pf_row = lane < cnt ? p.inst_row[r0 + lo + lane] : 0u;
+        pf_slot = lane < cnt ? p.slot_off[p.inst_row[r0 + lo + lane]] : 0u;
         pf_touch = lane < cnt ? rb_defined_touch(p.touch[(size_t)r0 + lo + lane], (uint32_t)(lo + lane), cov4) : 0u;
         const int lo2 = max(0, lo - 64), cnt2 = lo - lo2;
         ids_nxt = lane < cnt2 ? p.point_list[r0 + lo2 + lane] : 0u;
+        rows_nxt = lane < cnt2 ? p.inst_row[r0 + lo2 + lane] : 0u;
     }
 
     while (hi > 0) {
         const int lo = max(0, hi - 64), nb = hi - lo;
-        const uint32_t row_of_lane = pf_row;          // emission index of staged entry `lane`
         const uint32_t touch_of_lane = pf_touch;      // 4 bytes (one per quad) x 4 bits (one per 4x4 block): blended there?
         // first gradient row of staged entry `lane` (its rows are dense, in (quad, block) order of the set bits)
-        const uint32_t slot_of_lane = lane < nb ? p.slot_off[row_of_lane] : 0u;
+        const uint32_t slot_of_lane = pf_slot;
         // the record's two cull-rect words mean nothing to the backward: the staged copy carries the entry's first row
         // and its touch word there instead, so a block that picks entry j reads them with the record (they used to come
         // through two ds_bpermute per iteration)
@@ -220,11 +221,12 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
         {   // prefetch the next (shallower) batch
             const int hi2 = lo, lo2 = max(0, hi2 - 64), cnt = hi2 - lo2;
             GSR_GATHER5(ids_nxt, cnt);
-            pf_row = lane < cnt ? p.inst_row[r0 + lo2 + lane] : 0u;
+            pf_slot = lane < cnt ? p.slot_off[rows_nxt] : 0u;
             pf_touch = lane < cnt ? rb_defined_touch(p.touch[(size_t)r0 + lo2 + lane], (uint32_t)(lo2 + lane), cov4) : 0u;
             ids_cur = ids_nxt;
             const int lo3 = max(0, lo2 - 64), cnt3 = lo2 - lo3;
             ids_nxt = lane < cnt3 ? p.point_list[r0 + lo3 + lane] : 0u;
+            rows_nxt = lane < cnt3 ? p.inst_row[r0 + lo3 + lane] : 0u;
         }
         if (STAGE_FEAT) {
             // EVERY slot is written (zeros where the features were not fetched): a block whose mask is empty this
