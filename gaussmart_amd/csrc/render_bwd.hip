@@ -8,8 +8,9 @@
 // a tile's workgroup owns an 8x8 pixel quad and never synchronises with the other three; each DPP row of
 // 16 lanes owns one 4x4 pixel block of that quad and walks ITS OWN list:
 //   * the wave starts at the deepest list entry ANY OF ITS 64 PIXELS reached (quad-level, not tile-level)
-//     and walks the (tile, depth)-ordered list backwards, 64 entries per batch: ids two batches ahead,
-//     the 80-byte records gathered by id one batch ahead into registers, then into its private LDS slice;
+//     and walks the (tile, depth)-ordered list backwards, 64 entries per batch: ids two batches ahead, touch
+//     words and row slots one batch ahead, the 80-byte records gathered by id at the start of their batch (lane l
+//     fetches entry l) and staged in the wave's private LDS slice;
 //   * the forward left 4 bits per (instance, quad): "blended into >= 1 pixel of block g".  Four ballots
 //     turn them into one 64-bit to-do mask PER BLOCK; every iteration each row takes the deepest entry
 //     of its own mask, so the wave needs max_g |list_g| iterations instead of |union of the lists|
@@ -80,7 +81,7 @@ __device__ __forceinline__ uint32_t rb_defined_touch(uint32_t word, uint32_t pos
 }
 
 #ifndef RB_MIN_WAVES
-#define RB_MIN_WAVES 4   // <= 128 VGPRs, no scratch: measured 0.825 ms at 1M/1080p (5 waves spill: 1.13 ms)
+#define RB_MIN_WAVES 6   // <= 80 VGPRs; the kernel needs 72 without scratch, so seven waves per SIMD run (LDS: 7 x 20 KB)
 #endif
 // FEAT16: see render_fwd.hip -- 0 = RGB from the record, 1..4 = up to 16*FEAT16 feature channels by id.
 // PROBE (developer builds only: make PROBES=1, scripts/dev_probe.py): 1 = eight more dependent VALU per iteration,
@@ -184,12 +185,11 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
     uint32_t pf_slot = 0;    // first gradient row of the prefetched entry (slot_off[emission index]: a dependent load, so
                              // the emission indices run two batches ahead like the ids)
     int hi = max_contrib;
-    // ids run two batches ahead of the replay, records (and the per-entry words) one batch ahead
+    // ids and emission indices run two batches ahead of the replay, the per-entry words one batch ahead
     uint32_t ids_cur, ids_nxt, rows_nxt;
     {
         const int lo = max(0, hi - 64), cnt = hi - lo;
         ids_cur = lane < cnt ? p.point_list[r0 + lo + lane] : 0u;
-        GSR_GATHER5(ids_cur, cnt);
         pf_slot = lane < cnt ? p.slot_off[p.inst_row[r0 + lo + lane]] : 0u;
         pf_touch = lane < cnt ? rb_defined_touch(p.touch[(size_t)r0 + lo + lane], (uint32_t)(lo + lane), cov4) : 0u;
         const int lo2 = max(0, lo - 64), cnt2 = lo - lo2;
@@ -199,6 +199,11 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
 
     while (hi > 0) {
         const int lo = max(0, hi - 64), nb = hi - lo;
+        // The records of THIS batch are gathered here, not a batch ahead: holding the next batch's 20 registers per lane
+        // through the replay cost two waves per SIMD (92 VGPRs, 5 waves -> 72, 7 waves), and seven waves hide the gather's
+        // latency better than the prefetch did (K7 0.660 -> 0.640 ms same-box).  The ids, the touch
+        // words and the row slots -- five registers -- still run ahead.
+        GSR_GATHER5(ids_cur, nb);
         const uint32_t touch_of_lane = pf_touch;      // 4 bytes (one per quad) x 4 bits (one per 4x4 block): blended there?
         // first gradient row of staged entry `lane` (its rows are dense, in (quad, block) order of the set bits)
         const uint32_t slot_of_lane = pf_slot;
@@ -220,7 +225,6 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
         }
         {   // prefetch the next (shallower) batch
             const int hi2 = lo, lo2 = max(0, hi2 - 64), cnt = hi2 - lo2;
-            GSR_GATHER5(ids_nxt, cnt);
             pf_slot = lane < cnt ? p.slot_off[rows_nxt] : 0u;
             pf_touch = lane < cnt ? rb_defined_touch(p.touch[(size_t)r0 + lo2 + lane], (uint32_t)(lo2 + lane), cov4) : 0u;
             ids_cur = ids_nxt;
