@@ -33,6 +33,15 @@
         }                                                                                            \
     } while (0)
 
+#ifdef GSR_DEV_PROBES
+// PROBE 7: every wave leaves (start, end) on the 100 MHz s_memrealtime clock and its hardware id -- the occupancy of a
+// launch over time (scripts/dev_wave_timeline.py).  Developer builds only.
+#define RF_STAMP_WAVES 65536
+__device__ unsigned long long g_rf_stamps[3 * RF_STAMP_WAVES];
+extern "C" int gsr_probe_read_stamps(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rf_stamps), bytes < sizeof(g_rf_stamps) ? bytes : sizeof(g_rf_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
 #define RF_BLOCK 256
 #define RF_WAVES 4
 
@@ -83,6 +92,10 @@ __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : 2) rend
     // takes tile (b % 8) * per_xcd + b / 8 -- every XCD owns one contiguous band of tiles, and the records shared by
     // neighbouring tiles are fetched into ONE L2 instead of several
     const int tile_lin = (int)(blockIdx.x & 7u) * p.per_xcd + (int)(blockIdx.x >> 3);
+#ifdef GSR_DEV_PROBES
+    unsigned long long stamp_t0 = 0;
+    if (PROBE == 7) stamp_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (tile_lin >= p.n_tiles) return;
     const int tile_y = tile_lin / p.gx, tile_x = tile_lin - tile_y * p.gx;
     const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
@@ -278,6 +291,19 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
         p.out_allmap[pix_id + 5 * HW] = med_depth;
         p.out_allmap[pix_id + 6 * HW] = dist;
     }
+#ifdef GSR_DEV_PROBES
+    if (PROBE == 7) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const uint32_t w = blockIdx.x * 4u + (uint32_t)wave;
+        if (lane == 0 && w < RF_STAMP_WAVES) {
+            g_rf_stamps[3 * w] = stamp_t0; g_rf_stamps[3 * w + 1] = t1;
+            g_rf_stamps[3 * w + 2] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
+#endif
 }
 
 int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* splat,
@@ -305,6 +331,7 @@ int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float*
                 case 3: hipLaunchKernelGGL((render_fwd_kernel<0, true, 3>), grid, block, 0, s, p); break;
                 case 4: hipLaunchKernelGGL((render_fwd_kernel<0, true, 4>), grid, block, 0, s, p); break;
                 case 5: hipLaunchKernelGGL((render_fwd_kernel<0, true, 5>), grid, block, 0, s, p); break;
+                case 7: hipLaunchKernelGGL((render_fwd_kernel<0, true, 7>), grid, block, 0, s, p); break;
                 default: hipLaunchKernelGGL((render_fwd_kernel<0, true>), grid, block, 0, s, p);
             }
 #else
