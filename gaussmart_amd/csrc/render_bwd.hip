@@ -86,7 +86,7 @@ __device__ __forceinline__ uint32_t rb_defined_touch(uint32_t word, uint32_t pos
 // FEAT16: see render_fwd.hip -- 0 = RGB from the record, 1..4 = up to 16*FEAT16 feature channels by id.
 // PROBE (developer builds only: make PROBES=1, scripts/dev_probe.py): 1 = eight more dependent VALU per iteration,
 // 4 = eight more dependent SALU, 3 = no row store (WRONG gradients: it exists to time the loop), 6 = 20 KB more LDS per
-// workgroup (four waves per SIMD instead of five).
+// workgroup (fewer waves per SIMD), 8 = four LDS reads of the record instead of five (WRONG gradients).
 template <int FEAT16, int PROBE = 0>
 __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) render_bwd_kernel(RenderBwdParams p) {
     __shared__ float s_probe_pad[PROBE == 6 ? 5120 : 1];
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
             const bool has = jrev >= 0;
             const int j = (63 - jrev) & 63;
             const int cidx = lo + j;                            // 0-based position in the tile list
-            const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
+            const float4 a0 = s_rec[j * 5 + 0], a1 = PROBE == 8 ? a0 : s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
             const float4 a3 = s_rec[j * 5 + 3];
             // Branch-free: EVERY lane runs the gradient math (masked-off lanes would cost the same issue slots),
             // and a lane that does not blend this splat gets alpha = G = 0 and harmless finite geometry, which
@@ -543,6 +543,7 @@ int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32
             case 3: hipLaunchKernelGGL((render_bwd_kernel<0, 3>), grid, block, 0, s, p); break;
             case 4: hipLaunchKernelGGL((render_bwd_kernel<0, 4>), grid, block, 0, s, p); break;
             case 6: hipLaunchKernelGGL((render_bwd_kernel<0, 6>), grid, block, 0, s, p); break;
+            case 8: hipLaunchKernelGGL((render_bwd_kernel<0, 8>), grid, block, 0, s, p); break;
             default: hipLaunchKernelGGL((render_bwd_kernel<0>), grid, block, 0, s, p);
         }
 #else
