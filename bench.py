@@ -17,6 +17,7 @@ kernel (timed live with HIP events on the launch stream) and `cpu_baseline` (the
 oracle on a bounded sample of the same frame, on this box's host cores).
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -303,6 +304,12 @@ def main():
     def step(i):
         training_step(model, cam, gt, opt, pipe, bg, base_iter + i, view_parallel=vp, next_cam=next_cam)
 
+    # Python's cyclic garbage collector runs when allocation counts cross a threshold, i.e. at arbitrary steps, and a full
+    # collection stalls the host for a millisecond or more -- in a 20-step timed region that is several per cent of noise
+    # that has nothing to do with the device.  Collect now, keep it off while stepping (reference counting still frees
+    # everything the steps allocate), turn it back on after the measurements.
+    gc.collect()
+    gc.disable()
     log("target rendered; warm-up")
     if (vp is not None and os.environ.get("GSR_BENCH_HIGH_PRIORITY", "1") != "0") or os.environ.get("GSR_BENCH_HIGH_PRIORITY") == "1":
         # view-parallel step: the step itself runs on a HIGH-priority stream, so its short latency-bound kernels (sort
@@ -402,6 +409,7 @@ def main():
 
     # (b) the reference's own `iter_time` bracket (train.py:91,145: forward + loss + backward, no optimiser step) and
     # (c) inference frames the way render.py / view.py produce them (render() under no_grad: forward-only kernels)
+    gc.enable()
     ref_iter_ms = fwd_fps = None
     if rank == 0:
         if vp is not None:
