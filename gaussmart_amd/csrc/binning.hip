@@ -8,10 +8,12 @@
 //   3. a stable sort of the D instances by tile id only (ceil(log2 tiles) bits, 2 passes).
 // Stability makes ties fall back to emission order = (depth, Gaussian index), which is exactly the
 // order a stable sort of the 64-bit keys emitted in Gaussian-index order produces, so
-// `point_list` is bit-identical (checked against NumPy's stable argsort in tests/test_binning.py).
+// `point_list` is bit-identical (checked against NumPy's stable argsort in tests/test_gpu_rasterizer.py::test_binning_bit_exact
+// and tests/test_gpu_sort_knn.py).
 //
 // All integer work; HBM-bound.  Wave64 throughout: digit matching uses 64-bit ballots.
 #include "gsr_common.h"
+#include <type_traits>
 
 // ============================================================================ scan
 #define SCAN_BLOCK 256
@@ -128,6 +130,18 @@ int gsr_exclusive_scan_u8(const uint8_t* in, uint32_t* out, int64_t n, void* ws,
 }
 
 // ============================================================================ radix sort
+// One pass = TWO launches (round 3; rounds 1-2 ran histogram -> per-digit table scan -> scatter, and the scan was 64-256
+// workgroups walking `nblocks` counters serially: 10 us per pass at 1 M keys, 54 us at 22 M):
+//   rs_hist_kernel     one workgroup per GROUP of G consecutive tiles: per tile the digit counts of the group's earlier
+//                      tiles (`tile_pre`, exclusive, in-group), per group the totals (`group_tot`), and -- with one
+//                      256-byte-contiguous integer atomic wave-instruction per 64 digits -- the totals of the group's
+//                      SUPERGROUP of 32 groups (`super_tot`; <= 32 adders per row, the shape that runs at full rate);
+//   rs_scatter_kernel  every workgroup serves itself: digit base = scan over the digits of sum(super_tot), plus the
+//                      supergroups before its own (<= 64 rows), the groups before its own inside its supergroup (<= 31
+//                      rows), plus its tile_pre row.  All rows are block-major (one coalesced row of NB counters per load)
+//                      and L2-resident; the loads are issued behind the tile's own key loads.
+// G = smallest power of two with nblocks / G <= 512 (at most 32: the group's histograms live in LDS side by side), so up
+// to 33 M pairs there are at most 16 supergroups and a scatter workgroup fetches all its rows in one round trip.
 #define RS_BLOCK 256
 #define RS_WAVES (RS_BLOCK / 64)
 // 2048 pairs per workgroup: the depth sort of 1M Gaussians then has 489 workgroups (two per CU) instead of 245 (fewer
@@ -138,41 +152,70 @@ int gsr_exclusive_scan_u8(const uint8_t* in, uint32_t* out, int64_t n, void* ws,
 #endif
 #define RS_TILE (RS_BLOCK * RS_ITEMS)
 #define RS_MAX_BINS 256
+#define RS_SUPER 32          // groups per supergroup
+#define RS_MAX_G 32          // tiles per group at most (one LDS histogram per tile of the group: 32 KB)
+#define RS_GROUPS_TARGET 512 // => at most 16 supergroups (ONE batch of row loads per scatter workgroup) up to 33 M pairs
 
-__global__ void __launch_bounds__(RS_BLOCK) rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t n,
-                                                           int shift, uint32_t mask, int nbins,
-                                                           int nblocks, uint32_t* __restrict__ table) {
-    __shared__ uint32_t hist[RS_MAX_BINS];
-    for (int i = threadIdx.x; i < nbins; i += RS_BLOCK) hist[i] = 0;
+struct RsGeom {
+    int nblocks, G, ngroups, nsuper;
+    explicit RsGeom(int64_t n) {
+        nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
+        if (nblocks < 1) nblocks = 1;
+        G = 1;
+        while ((nblocks + G - 1) / G > RS_GROUPS_TARGET && G < RS_MAX_G) G <<= 1;
+        ngroups = (nblocks + G - 1) / G;
+        nsuper = (ngroups + RS_SUPER - 1) / RS_SUPER;
+    }
+};
+
+__global__ void __launch_bounds__(RS_BLOCK) rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
+                                                           uint32_t mask, int nbins, int nblocks, int G,
+                                                           uint32_t* __restrict__ tile_pre,
+                                                           uint32_t* __restrict__ group_tot,
+                                                           uint32_t* __restrict__ super_tot) {
+    extern __shared__ uint32_t hist[];   // [tiles of this group][nbins]
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * G, t1 = min(nblocks, t0 + G), nt = t1 - t0;
+    for (int i = tid; i < nt * nbins; i += RS_BLOCK) hist[i] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    // no barrier between the tiles of the group: their loads are independent, U tiles (8 U keys per thread) are in
+    // flight at a time
+    auto count_tiles = [&](auto U_) {
+        constexpr int U = decltype(U_)::value;
+        for (int t = 0; t < nt; t += U) {
+            uint32_t k[U][RS_ITEMS];
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS; ++i) {
-        const int64_t j = base + (int64_t)i * RS_BLOCK + threadIdx.x;
-        if (j < n) atomicAdd(&hist[(keys[j] >> shift) & mask], 1u);
-    }
+            for (int u = 0; u < U; ++u) {
+                const int64_t base = (int64_t)(t0 + t + u) * RS_TILE + tid;
+#pragma unroll
+                for (int i = 0; i < RS_ITEMS; ++i) {
+                    const int64_t j = base + (int64_t)i * RS_BLOCK;
+                    k[u][i] = (t + u < nt && j < n) ? keys[j] : 0u;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t base = (int64_t)(t0 + t + u) * RS_TILE + tid;
+                uint32_t* h = hist + (t + u) * nbins;
+#pragma unroll
+                for (int i = 0; i < RS_ITEMS; ++i)
+                    if (t + u < nt && base + (int64_t)i * RS_BLOCK < n) atomicAdd(&h[(k[u][i] >> shift) & mask], 1u);
+            }
+        }
+    };
+    if (G >= 4) count_tiles(std::integral_constant<int, 4>{});
+    else if (G == 2) count_tiles(std::integral_constant<int, 2>{});
+    else count_tiles(std::integral_constant<int, 1>{});
     __syncthreads();
-    // digit-major table: an exclusive scan over it is the global base of (digit, block)
-    for (int i = threadIdx.x; i < nbins; i += RS_BLOCK) table[(size_t)i * nblocks + blockIdx.x] = hist[i];
-}
-
-// Per digit (one workgroup each): exclusive prefix of the digit's counts over the tiles, in place, plus the digit total.
-// The table is digit-major, so a workgroup reads one contiguous row.  Together with the 256-value scan of the totals
-// that every scatter workgroup does for itself, this replaces a generic two-launch scan of the whole table.
-__global__ void __launch_bounds__(RS_BLOCK) rs_digit_scan_kernel(uint32_t* __restrict__ table, int nblocks,
-                                                                 uint32_t* __restrict__ digit_total) {
-    __shared__ uint32_t wt[RS_WAVES];
-    uint32_t* row = table + (size_t)blockIdx.x * nblocks;
-    uint32_t carry = 0;
-    for (int base = 0; base < nblocks; base += RS_BLOCK) {
-        const int j = base + threadIdx.x;
-        const uint32_t v = j < nblocks ? row[j] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_excl_scan(v, total, wt);
-        if (j < nblocks) row[j] = carry + ex;
-        carry += total;
+    if (tid < nbins) {
+        uint32_t run = 0;
+        for (int t = 0; t < nt; ++t) {
+            tile_pre[(size_t)(t0 + t) * nbins + tid] = run;
+            run += hist[t * nbins + tid];
+        }
+        group_tot[(size_t)blockIdx.x * nbins + tid] = run;
+        atomicAdd(&super_tot[(size_t)(blockIdx.x / RS_SUPER) * nbins + tid], run);
     }
-    if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
 }
 
 // V2: a SECOND value array travels with the pairs (the tile sort carries the Gaussian id next to the emission index, so
@@ -182,9 +225,11 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_scatter_kernel(const uint32_t* __
                                                               const uint32_t* __restrict__ vals_in,
                                                               uint32_t* __restrict__ keys_out,
                                                               uint32_t* __restrict__ vals_out, int64_t n,
-                                                              int shift, int nblocks,
-                                                              const uint32_t* __restrict__ table_scanned,
-                                                              const uint32_t* __restrict__ digit_total,
+                                                              int shift, int G, int nsuper,
+                                                              const uint32_t* __restrict__ tile_pre,
+                                                              const uint32_t* __restrict__ group_tot,
+                                                              const uint32_t* __restrict__ super_tot,
+                                                              uint32_t* __restrict__ super_next,
                                                               const uint32_t* __restrict__ vals2_in,
                                                               uint32_t* __restrict__ vals2_out) {
     constexpr int NB = 1 << BITS;
@@ -198,21 +243,12 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_scatter_kernel(const uint32_t* __
     __shared__ uint32_t wt[RS_WAVES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < RS_WAVES * NB; i += RS_BLOCK) (&wave_hist[0][0])[i] = 0;
-    __syncthreads();
-    {   // global base of (digit, this tile) = first output index of the digit + the digit's count in earlier tiles
-        uint32_t tot_unused;
-        const uint32_t dbase = block_excl_scan(tid < NB ? digit_total[tid] : 0u, tot_unused, wt);
-        if (tid < NB) gbase[tid] = dbase + table_scanned[(size_t)tid * nblocks + blockIdx.x];
-    }
-    __syncthreads();
-
     const int64_t block_base = (int64_t)blockIdx.x * RS_TILE;
     const int block_n = (int)min((int64_t)RS_TILE, n - block_base);
     const int wave_base_idx = wave * (RS_TILE / RS_WAVES);
 
+    // the tile's own loads go out first; the table rows below arrive while they are in flight
     uint32_t key[RS_ITEMS], val[RS_ITEMS], val2[V2 ? RS_ITEMS : 1], rank[RS_ITEMS];
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const int local = wave_base_idx + r * 64 + lane;   // index order = (wave, round, lane)
@@ -221,6 +257,47 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_scatter_kernel(const uint32_t* __
         // vals_in == NULL means "values are the element indices" (first pass of an argsort)
         val[r] = valid ? (vals_in ? vals_in[block_base + local] : (uint32_t)(block_base + local)) : 0u;
         if (V2) val2[r] = valid ? vals2_in[block_base + local] : 0u;
+    }
+    for (int i = tid; i < RS_WAVES * NB; i += RS_BLOCK) (&wave_hist[0][0])[i] = 0;
+    // the next pass's histogram kernel accumulates into the other supergroup table: left zeroed here
+    if (blockIdx.x == 0 && super_next)
+        for (int i = tid; i < nsuper * RS_MAX_BINS; i += RS_BLOCK) super_next[i] = 0;
+    {   // global base of (digit, this tile) = first output index of the digit + the digit's count in earlier tiles.
+        // Every row load is independent of the others and issued before any is consumed (fixed trip counts, clamped row
+        // index + select): one L2 round trip for the lot, behind the tile's own loads.  (Keeping the rows in registers
+        // until after the ranking instead costs 50 VGPRs = half the occupancy: measured slower from 3 M pairs up.)
+        uint32_t tot = 0, before = 0;
+        if (tid < NB) {
+            const int g = (int)blockIdx.x / G, sg = g / RS_SUPER, g0 = sg * RS_SUPER;
+            const uint32_t pre = tile_pre[(size_t)blockIdx.x * NB + tid];
+            uint32_t gv[RS_SUPER - 1];
+#pragma unroll
+            for (int k = 0; k < RS_SUPER - 1; ++k) gv[k] = group_tot[(size_t)min(g0 + k, g) * NB + tid];
+            for (int q0 = 0; q0 < nsuper; q0 += 16) {
+                uint32_t sv[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sv[k] = super_tot[(size_t)min(q0 + k, nsuper - 1) * NB + tid];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t v = q0 + k < nsuper ? sv[k] : 0u;
+                    tot += v;
+                    before += q0 + k < sg ? v : 0u;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RS_SUPER - 1; ++k) before += g0 + k < g ? gv[k] : 0u;
+            before += pre;
+        }
+        uint32_t tot_unused;
+        const uint32_t dbase = block_excl_scan(tot, tot_unused, wt);   // (two barriers: wave_hist is zeroed behind them)
+        if (tid < NB) gbase[tid] = dbase + before;
+    }
+
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const int local = wave_base_idx + r * 64 + lane;
+        const bool valid = local < block_n;
         const uint32_t d = (key[r] >> shift) & MASK;
         // lanes holding the same digit (among valid lanes)
         unsigned long long same = __ballot(valid);
@@ -292,15 +369,11 @@ __global__ void iota_kernel(uint32_t* out, int64_t n) {
     if (i < n) out[i] = (uint32_t)i;
 }
 
-static size_t rs_table_entries(int64_t n) {
-    const int64_t nblocks = (n + RS_TILE - 1) / RS_TILE;
-    return size_t(nblocks > 0 ? nblocks : 1) * RS_MAX_BINS;
-}
-
 size_t gsr_sort_ws_bytes(int64_t n) {
-    // table (raw, scanned in place per digit) + digit totals
-    const size_t e = rs_table_entries(n);
-    return gsr_align(e * 4) + gsr_align(RS_MAX_BINS * 4);
+    // tile_pre [nblocks][256] + group_tot [ngroups][256] + two supergroup tables (this pass / next pass)
+    const RsGeom geo(n);
+    return gsr_align(size_t(geo.nblocks) * RS_MAX_BINS * 4) + gsr_align(size_t(geo.ngroups) * RS_MAX_BINS * 4) +
+           2 * gsr_align(size_t(geo.nsuper) * RS_MAX_BINS * 4);
 }
 
 int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
@@ -319,10 +392,16 @@ int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint3
         return GSR_OK;
     }
     const int passes = (bits + 7) / 8;
-    const int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
-    const size_t e = rs_table_entries(n);
-    uint32_t* table = static_cast<uint32_t*>(ws);
-    uint32_t* digit_total = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + gsr_align(e * 4));
+    const RsGeom geo(n);
+    char* w8 = static_cast<char*>(ws);
+    uint32_t* tile_pre = reinterpret_cast<uint32_t*>(w8);
+    uint32_t* group_tot = reinterpret_cast<uint32_t*>(w8 + gsr_align(size_t(geo.nblocks) * RS_MAX_BINS * 4));
+    const size_t super_bytes = gsr_align(size_t(geo.nsuper) * RS_MAX_BINS * 4);
+    uint32_t* super_tab[2];
+    super_tab[0] = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(group_tot) + gsr_align(size_t(geo.ngroups) * RS_MAX_BINS * 4));
+    super_tab[1] = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(super_tab[0]) + super_bytes);
+    // the first pass's supergroup table is zeroed here, every later one by the scatter kernel of the pass before it
+    GSR_HIP_CHECK(hipMemsetAsync(super_tab[0], 0, size_t(geo.nsuper) * RS_MAX_BINS * 4, s));
 
     // ping-pong so that the last pass lands in *_out
     const uint32_t* src_k = keys_in; const uint32_t* src_v = vals_in; const uint32_t* src_v2 = vals2_in;
@@ -336,21 +415,19 @@ int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint3
         uint32_t* dst_k = to_out ? keys_out : keys_tmp;
         uint32_t* dst_v = to_out ? vals_out : vals_tmp;
         uint32_t* dst_v2 = to_out ? vals2_out : vals2_tmp;
+        uint32_t* sup = super_tab[p & 1];
+        uint32_t* sup_next = p + 1 < passes ? super_tab[(p + 1) & 1] : nullptr;
         {
             GsrProfileScope prof(GSR_K_SORT_HIST, s);
-            hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_BLOCK), 0, s, src_k, n, bit,
-                               (uint32_t)(nbins - 1), nbins, nblocks, table);
-        }
-        {
-            GsrProfileScope prof(GSR_K_SCAN, s);
-            hipLaunchKernelGGL(rs_digit_scan_kernel, dim3(nbins), dim3(RS_BLOCK), 0, s, table, nblocks, digit_total);
+            hipLaunchKernelGGL(rs_hist_kernel, dim3(geo.ngroups), dim3(RS_BLOCK), size_t(geo.G) * nbins * 4, s, src_k, n, bit,
+                               (uint32_t)(nbins - 1), nbins, geo.nblocks, geo.G, tile_pre, group_tot, sup);
         }
         {
             GsrProfileScope prof(GSR_K_SORT_SCATTER, s);
-#define RS_CASE(B) case B: if (v2) hipLaunchKernelGGL((rs_scatter_kernel<B, true>), dim3(nblocks), dim3(RS_BLOCK), 0, s, \
-                                              src_k, src_v, dst_k, dst_v, n, bit, nblocks, table, digit_total, src_v2, dst_v2); \
-                   else hipLaunchKernelGGL((rs_scatter_kernel<B, false>), dim3(nblocks), dim3(RS_BLOCK), 0, s, \
-                                              src_k, src_v, dst_k, dst_v, n, bit, nblocks, table, digit_total, nullptr, nullptr); break;
+#define RS_CASE(B) case B: if (v2) hipLaunchKernelGGL((rs_scatter_kernel<B, true>), dim3(geo.nblocks), dim3(RS_BLOCK), 0, s, \
+                                              src_k, src_v, dst_k, dst_v, n, bit, geo.G, geo.nsuper, tile_pre, group_tot, sup, sup_next, src_v2, dst_v2); \
+                   else hipLaunchKernelGGL((rs_scatter_kernel<B, false>), dim3(geo.nblocks), dim3(RS_BLOCK), 0, s, \
+                                              src_k, src_v, dst_k, dst_v, n, bit, geo.G, geo.nsuper, tile_pre, group_tot, sup, sup_next, nullptr, nullptr); break;
             switch (w) { RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
                 default: gsr_set_error("radix digit width %d", w); return GSR_E_INVALID; }
 #undef RS_CASE

@@ -24,6 +24,10 @@ class FusedAdam(torch.optim.Adam):
         self.color_cache = None
         self._cache_buf = None
         self._xyz_old = None
+        # every kernel of this optimiser writes parameters through raw pointers, which torch's version counters never see:
+        # the cache key therefore carries this counter, bumped by every call that updates parameters (a cache is keyed
+        # with the value it has AFTER the call that built it)
+        self._writes = 0
 
     # ---- factored SH gradient: the two feature parameters have NO .grad after such a backward; their gradient is the
     # record parked here, which the next full step() turns into an update (so `optimizer.step()` keeps meaning "apply
@@ -48,13 +52,18 @@ class FusedAdam(torch.optim.Adam):
         self.pending_sh = None
         return super().zero_grad(set_to_none=set_to_none)
 
-    @staticmethod
-    def color_cache_key(campos, sh_degree, xyz, f_dc, f_rest):
+    def color_cache_key(self, campos, sh_degree, xyz, f_dc, f_rest):
         """What a colour cache is valid for: the view (its camera-centre tensor), the active degree and the exact parameter
         tensors in their current state.  torch's version counters catch every in-place modification made through torch;
-        the optimiser's own kernels write through raw pointers BEFORE the cache is built, so they do not disturb it."""
+        the optimiser's own kernels write through raw pointers, so its write counter is part of the key: any later
+        step() / step_slice() / step_sh_factored() -- with or without a next view -- retires the cache."""
         return (campos.data_ptr(), int(sh_degree), int(xyz.shape[0]), xyz.data_ptr(), f_dc.data_ptr(), f_rest.data_ptr(),
-                xyz._version, f_dc._version, f_rest._version, campos._version)
+                xyz._version, f_dc._version, f_rest._version, campos._version, self._writes)
+
+    def invalidate_color_cache(self):
+        """For code that rewrites parameters behind torch's back (`.data` copies, broadcasts into `.data`, raw pointers)."""
+        self._writes += 1
+        self.color_cache = None
 
     def lookup_color_cache(self, campos, sh_degree, xyz, f_dc, f_rest):
         """The cache tensor if the last factored step prepared the colour of exactly this view for exactly these
@@ -70,6 +79,7 @@ class FusedAdam(torch.optim.Adam):
         `stream`: torch.cuda.Stream to launch on instead of the current one.  Both serve the pipelined
         data-parallel step, which updates the geometry tensors and the SH tensors at different times."""
         only_ids = None if only is None else {id(p) for p in only}
+        self._writes += 1
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -159,6 +169,7 @@ class FusedAdam(torch.optim.Adam):
         group = next(g for g in self.param_groups if any(q is p for q in g["params"]))
         if p.grad is None or stop <= start:
             return
+        self._writes += 1
         if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
             raise _lib.GsrError("FusedAdam needs contiguous float32 parameters and gradients on a HIP device")
         st = self.state[p]
@@ -201,6 +212,7 @@ class FusedAdam(torch.optim.Adam):
         count = N - first if count is None else count
         if count <= 0:
             return
+        self._writes += 1
         for t in (f_dc, f_rest, xyz, records):
             if t.device.type != "cuda" or t.dtype != torch.float32 or not t.is_contiguous():
                 raise _lib.GsrError("step_sh_factored needs contiguous float32 tensors on a HIP device")

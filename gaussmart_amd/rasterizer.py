@@ -264,6 +264,18 @@ class ColorGradRecord:
 _COLOR_GRAD = {}     # (device, model key) -> ColorGradRecord of that model's last factored backward
 
 
+def _store_color_grad(device, xyz, rec):
+    """Most recent record LAST (a re-assigned dict key keeps its old position, so pop first), and slots whose model is
+    gone -- the xyz tensor they were keyed by was replaced by a densification and freed -- are retired with their
+    streams / events instead of accumulating."""
+    key = (device, _model_key(xyz))
+    _COLOR_GRAD.pop(key, None)
+    for k in [k for k, r in _COLOR_GRAD.items() if k[0] == device and (r.xyz is None or r.xyz.data_ptr() != k[1])]:
+        _COLOR_GRAD.pop(k, None)
+        _PENDING_PARAM_EVENT.pop(k, None)
+    _COLOR_GRAD[key] = rec
+
+
 def take_color_grad(model_or_device):
     """The ColorGradRecord the last factored backward left (None if there was none); clears the slot.  Pass the model's
     xyz parameter: records are kept per model, so two models training on one device do not see each other's.  A device
@@ -531,8 +543,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         del keep
         _finish_lease(ctx)
         if factored:
-            _COLOR_GRAD[(torch.device(device), _model_key(xyz))] = ColorGradRecord(flat, flat[:n_head], record, N, ctx.M,
-                                                                                   rs.sh_degree, xyz)
+            _store_color_grad(torch.device(device), xyz, ColorGradRecord(flat, flat[:n_head], record, N, ctx.M,
+                                                                          rs.sh_degree, xyz))
         return d_xyz, d_2d, d_dc, d_rest, d_op, d_sc, d_rot, None, None, None
 
 

@@ -70,7 +70,8 @@ def main(argv=None):
         model_params, first_iter = torch.load(args.start_checkpoint, map_location=dev, weights_only=True)
         gaussians.restore(model_params, opt)
     background = torch.tensor([1.0, 1.0, 1.0] if args.white_background else [0.0, 0.0, 0.0], device=dev)
-    # one rank: no exchange, but the same step pipeline (SH update on a side stream beside the next forward's binning)
+    # one rank: no exchange; past the densification phase train() takes the same pipelined step as N > 1 (SH update on a
+    # side stream beside the next forward's binning), before it the serial step behind the densification bookkeeping
     vp = ViewParallel(gaussians) if world > 1 else ViewParallel(gaussians, overlap_local=True)
 
     os.makedirs(args.model_path, exist_ok=True)

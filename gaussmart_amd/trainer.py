@@ -182,18 +182,30 @@ def train(gaussians, cameras, opt, pipe, background, *, cameras_extent=1.0, firs
         cam = st.next_cam if st.next_cam is not None else st.draw(cameras, view_parallel)
         st.next_cam = st.draw(cameras, view_parallel)
         gt = cam.original_image.to(device)
-        # the optimizer step comes after the densification bookkeeping, as in the reference
-        render_pkg, last = training_step(gaussians, cam, gt, opt, pipe, background, iteration,
-                                         view_parallel=view_parallel, step_optimizer=False,
-                                         next_cam=st.next_cam if iteration < final_iteration else None)
-        densification_step(gaussians, render_pkg, opt, iteration, cameras_extent, white_background, view_parallel)
-        if iteration < final_iteration:
-            optimizer_step(gaussians)      # the exchange of a view-parallel run already happened in training_step
+        nxt = st.next_cam if iteration < final_iteration else None
+        if view_parallel is not None and iteration >= opt.densify_until_iter and iteration < final_iteration:
+            # past the densification phase (train.py:198: `if iteration < opt.densify_until_iter`) nothing sits between the
+            # backward and the optimiser step, so the iteration takes the pipelined step of ViewParallel.reduce_and_step --
+            # the step bench.py times: the SH update (and, for N > 1, the colour-gradient all-gather) on the side stream
+            # beside the next forward's binning
+            render_pkg, last = training_step(gaussians, cam, gt, opt, pipe, background, iteration,
+                                             view_parallel=view_parallel, step_optimizer=True, next_cam=nxt)
         else:
-            gaussians.optimizer.zero_grad(set_to_none=True)   # the schedule's last iteration: no step (train.py:214)
+            # the optimizer step comes after the densification bookkeeping, as in the reference
+            render_pkg, last = training_step(gaussians, cam, gt, opt, pipe, background, iteration,
+                                             view_parallel=view_parallel, step_optimizer=False, next_cam=nxt)
+            densification_step(gaussians, render_pkg, opt, iteration, cameras_extent, white_background, view_parallel)
+            if iteration < final_iteration:
+                optimizer_step(gaussians)      # the exchange of a view-parallel run already happened in training_step
+            else:
+                gaussians.optimizer.zero_grad(set_to_none=True)   # the schedule's last iteration: no step (train.py:214)
         if on_iteration is not None:
             on_iteration(iteration)
         if log_every and iteration % log_every == 0:
+            if view_parallel is not None:
+                view_parallel.finish()
             log_fn(f"[it {iteration}] loss {float(last['loss']):.5f} points {gaussians.get_xyz.shape[0]} "
                    f"{(iteration - first_iter) / (time.time() - t0):.2f} it/s")
+    if view_parallel is not None:
+        view_parallel.finish()       # a pipelined last step may still be updating the SH tensors on its side stream
     return last

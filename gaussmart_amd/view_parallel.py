@@ -105,6 +105,10 @@ class ViewParallel:
                         c = c.to(p.device)
                     dist.broadcast(c, src=0, group=self.pg)
                     st["step"].fill_(float(c.item()))
+        # the parameters were rewritten through `.data` (no version bump): a colour cache built from the old ones is stale
+        for opt in {id(o): o for o in (optimizer, getattr(self.g, "optimizer", None)) if o is not None}.values():
+            if hasattr(opt, "invalidate_color_cache"):
+                opt.invalidate_color_cache()
 
     @property
     def world_size(self):

@@ -103,3 +103,39 @@ def test_training_with_colour_cache_tracks_training_without(gpu_device, overlap)
     for a, b in zip(runs[0][1], runs[1][1]):
         assert abs(a - b) <= 1e-4 * abs(a)
     assert runs[1][1][-1] < runs[1][1][0]
+
+
+def test_optimiser_writes_retire_the_cache(gpu_device):
+    """The optimiser's kernels write parameters through raw pointers (no torch version bump): a step WITHOUT a next view, a
+    partial step and a slice step must each retire a cache an earlier step built, or a later forward of that view would
+    render colours of parameters that are steps old."""
+    from gaussmart_amd.gaussian_renderer import render
+    from gaussmart_amd.trainer import training_step
+    fresh, cams, gts, pipe, opt, bg = _setup(gpu_device, n=5000)
+    m = fresh()
+    o = m.optimizer
+    look = lambda cam: o.lookup_color_cache(cam.camera_center, m.active_sh_degree, m._xyz, m._features_dc, m._features_rest)
+    training_step(m, cams[0], gts[0], opt, pipe, bg, 10000, next_cam=cams[0])
+    assert look(cams[0]) is not None
+    training_step(m, cams[0], gts[0], opt, pipe, bg, 10001, next_cam=None)       # parameters move, no new cache
+    assert look(cams[0]) is None
+    with torch.no_grad():                                                         # the forward runs the ordinary colour pass
+        a = render(cams[0], m, pipe, bg)["render"].clone()
+        o.color_cache = None
+        b = render(cams[0], m, pipe, bg)["render"]
+    assert torch.equal(a, b)
+    # partial and slice updates retire it too
+    training_step(m, cams[0], gts[0], opt, pipe, bg, 10002, next_cam=cams[1])
+    assert look(cams[1]) is not None
+    m._xyz.grad = torch.zeros_like(m._xyz)
+    o.step(only=[m._xyz])
+    assert look(cams[1]) is None
+    training_step(m, cams[0], gts[0], opt, pipe, bg, 10003, next_cam=cams[1])
+    assert look(cams[1]) is not None
+    m._opacity.grad = torch.zeros_like(m._opacity)
+    o.step_slice(m._opacity, 0, 10)
+    assert look(cams[1]) is None
+    training_step(m, cams[0], gts[0], opt, pipe, bg, 10004, next_cam=cams[1])
+    assert look(cams[1]) is not None
+    o.invalidate_color_cache()
+    assert look(cams[1]) is None
