@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const T* __restr
 
 size_t gsr_scan_workspace_bytes(int64_t n) {
     const int64_t blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
-    return gsr_align(size_t(blocks > 0 ? blocks : 1) * 4);
+    return gsr_align(size_t(blocks > 2 * GSR_COUNT_PARTIALS ? blocks : 2 * GSR_COUNT_PARTIALS) * 4);   // (also holds gsr_forward's count partials)
 }
 
 template <typename T>
@@ -440,6 +440,35 @@ int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint3
 }
 
 // ============================================================================ emit / finalize
+// Instance count ahead of the depth sort: partial sums of tiles_touched (the host adds <= 256 words), so that the one
+// host round trip of the forward overlaps the depth sort instead of following the scan.
+__global__ void __launch_bounds__(256) count_partials_kernel(const uint32_t* __restrict__ counts, int N, int chunk,
+                                                             unsigned long long* __restrict__ partial) {
+    __shared__ unsigned long long wt[4];
+    const int begin = blockIdx.x * chunk, end = min(N, begin + chunk);
+    unsigned long long sum = 0;     // 64-bit: a scene that overflows the 32-bit instance indices must be SEEN to
+    for (int i = begin + threadIdx.x; i < end; i += 256) sum += counts[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
+    if ((threadIdx.x & 63) == 0) wt[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = wt[0] + wt[1] + wt[2] + wt[3];
+}
+
+int gsr_launch_count_partials(const uint32_t* counts, int N, unsigned long long* partial, int* n_partial, hipStream_t s) {
+    int blocks = (N + 4095) / 4096;
+    if (blocks > GSR_COUNT_PARTIALS) blocks = GSR_COUNT_PARTIALS;
+    if (blocks < 1) blocks = 1;
+    const int chunk = ((N + blocks - 1) / blocks + 255) & ~255;
+    blocks = (N + chunk - 1) / chunk;
+    if (blocks < 1) blocks = 1;
+    *n_partial = blocks;
+    GsrProfileScope prof(GSR_K_SCAN, s);
+    hipLaunchKernelGGL(count_partials_kernel, dim3(blocks), dim3(256), 0, s, counts, N, chunk, partial);
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}
+
 // Tile rects in depth-rank order: ONE gather by Gaussian id; the scan of the counts and the emission below then
 // read everything coalesced (before, the scan gathered tiles_touched twice and emit gathered four arrays).
 __global__ void __launch_bounds__(256) rank_gather_kernel(int N, const uint32_t* __restrict__ order,

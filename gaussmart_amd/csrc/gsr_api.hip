@@ -143,13 +143,14 @@ static int validate(const GsrView* v, const GsrGaussians* g) {
     return GSR_OK;
 }
 
-// 4 bytes of pinned host memory per calling thread, for the one device -> host read of gsr_forward; allocated on
-// first use and kept (a forward is synchronous with respect to this read, so one slot per thread suffices).
+// 2 KiB of pinned host memory per calling thread, for the one device -> host read of gsr_forward (the partial sums of
+// the instance count); allocated on first use and kept (a forward is synchronous with respect to this read, so one slot
+// per thread suffices).
 static uint32_t* pinned_counter() {
-    thread_local uint32_t* slot = nullptr;
+    thread_local uint32_t* slot = nullptr;   // (8-byte aligned: also read as 64-bit words)
     if (!slot) {
         void* p = nullptr;
-        if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (hipHostMalloc(&p, GSR_COUNT_PARTIALS * 8, hipHostMallocDefault) != hipSuccess) return nullptr;
         slot = static_cast<uint32_t*>(p);
     }
     return slot;
@@ -253,31 +254,39 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
                 color_join.done = ev2[1]; color_join.armed = true;
             }
         }
-        // depth order of the Gaussians (stable; culled ones carry key 0xFFFFFFFF and no tiles)
-        rc = gsr_radix_sort_pairs(depth_key, nullptr, keys_sorted, order, keys_tmp, vals_tmp, N, 0, 32, sort_ws, s);
-        if (rc != GSR_OK) return rc;
-        rc = gsr_launch_rank_gather(N, order, tile_rect, rank_rect, rank_cnt, s);
-        if (rc != GSR_OK) return rc;
-        rc = gsr_exclusive_scan_u32(rank_cnt, nullptr, offs, N, scan_ws, s);
-        if (rc != GSR_OK) return rc;
-        // The instance count sizes the next buffers, so the host has to see it: the copy is followed by
-        // an event, and the SH colour pass is enqueued BEHIND that event so that it runs during the
-        // host round trip (wait on the event, allocate, launch) instead of leaving the GPU idle.
+        // The instance count D = sum of tiles_touched sizes the next buffers, so the host has to see it.  It does not
+        // depend on the depth order: partial sums are taken right behind the geometry pass and copied out, and the
+        // depth sort, the rank gather and the scan are enqueued BEHIND that copy -- the host round trip (wait on the
+        // event, allocate, launch) is over long before they are, so the stream never drains.  (Rounds 1-2 read the
+        // scan's total back, with nothing but the colour pass behind it: with the colour pass on another stream the
+        // main stream idled for the round trip.)
         // The destination must be PINNED: a copy into pageable memory blocks the host inside hipMemcpyAsync
-        // until the data has arrived, the colour pass is then launched late and the GPU idles ~40 us.
-        uint32_t* d_host = pinned_counter();
+        // until the data has arrived.
+        unsigned long long* d_host = reinterpret_cast<unsigned long long*>(pinned_counter());
         if (!d_host) { gsr_set_error("hipHostMalloc failed (instance-count read-back buffer)"); return GSR_E_HIP; }
+        unsigned long long* d_partial = static_cast<unsigned long long*>(scan_ws);   // (the scan below overwrites it after the copy)
+        int n_partial = 0;
+        rc = gsr_launch_count_partials(tiles_touched, N, d_partial, &n_partial, s);
+        if (rc != GSR_OK) return rc;
         hipEvent_t ev;
         GSR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        hipError_t e1 = hipMemcpyAsync(d_host, offs + N, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        hipError_t e1 = hipMemcpyAsync(d_host, d_partial, size_t(n_partial) * 8, hipMemcpyDeviceToHost, s);
         hipError_t e2 = e1 == hipSuccess ? hipEventRecord(ev, s) : e1;
-        if (!defer_color)
-            rc = e2 == hipSuccess ? gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, color_jac, s) : GSR_OK;
+        if (e2 == hipSuccess && !defer_color)
+            rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, color_jac, s);
+        // depth order of the Gaussians (stable; culled ones carry key 0xFFFFFFFF and no tiles)
+        if (e2 == hipSuccess && rc == GSR_OK)
+            rc = gsr_radix_sort_pairs(depth_key, nullptr, keys_sorted, order, keys_tmp, vals_tmp, N, 0, 32, sort_ws, s);
+        if (e2 == hipSuccess && rc == GSR_OK) rc = gsr_launch_rank_gather(N, order, tile_rect, rank_rect, rank_cnt, s);
+        if (e2 == hipSuccess && rc == GSR_OK) rc = gsr_exclusive_scan_u32(rank_cnt, nullptr, offs, N, scan_ws, s);
         hipError_t e3 = e2 == hipSuccess ? hipEventSynchronize(ev) : e2;   // the one host wait of the forward
         (void)hipEventDestroy(ev);
         GSR_HIP_CHECK(e3);
-        D = *d_host;
         if (rc != GSR_OK) return rc;
+        uint64_t total = 0;
+        for (int i = 0; i < n_partial; ++i) total += d_host[i];
+        if (total > 0x7FFFFFF0ull) { gsr_set_error("instance count %llu overflows", (unsigned long long)total); return GSR_E_UNSUPPORTED; }
+        D = (uint32_t)total;
     }
     if (D > 0x7FFFFFF0u) { gsr_set_error("instance count %u overflows", D); return GSR_E_UNSUPPORTED; }
     out->num_rendered = (int32_t)D;

@@ -129,6 +129,9 @@ int gsr_launch_preprocess_color(const GsrView& v, const GsrGaussians& g, float* 
                                 int32_t* radii, float* color_jac /* [N,9] or NULL */, hipStream_t s);
 // does the colour pass of this call leave d(rgb)/d(dir) (forward and backward must agree)?
 bool gsr_color_jac_available(const GsrView& v, const GsrGaussians& g);
+// 64-bit partial sums of counts[0..N) (<= GSR_COUNT_PARTIALS of them, *n_partial says how many): the host adds them up
+#define GSR_COUNT_PARTIALS 256
+int gsr_launch_count_partials(const uint32_t* counts, int N, unsigned long long* partial, int* n_partial, hipStream_t s);
 int gsr_launch_rank_gather(int N, const uint32_t* order, const uint2* tile_rect, uint2* rank_rect, uint32_t* rank_cnt,
                            hipStream_t s);
 int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const uint32_t* offs,
