@@ -376,10 +376,20 @@ size_t gsr_sort_ws_bytes(int64_t n) {
            2 * gsr_align(size_t(geo.nsuper) * RS_MAX_BINS * 4);
 }
 
+// The words of the workspace that must be zero when the first pass starts (its supergroup table).  gsr_radix_sort_pairs
+// clears them itself (one memset launch, ~5 us) unless the caller says a kernel of its own already did.
+void gsr_sort_zero_region(void* ws, int64_t n, uint32_t** ptr, size_t* words) {
+    const RsGeom geo(n > 0 ? n : 1);
+    char* w8 = static_cast<char*>(ws);
+    *ptr = reinterpret_cast<uint32_t*>(w8 + gsr_align(size_t(geo.nblocks) * RS_MAX_BINS * 4) +
+                                       gsr_align(size_t(geo.ngroups) * RS_MAX_BINS * 4));
+    *words = size_t(geo.nsuper) * RS_MAX_BINS;
+}
+
 int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
                          uint32_t* vals_out, uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n,
                          int begin_bit, int end_bit, void* ws, hipStream_t s,
-                         const uint32_t* vals2_in, uint32_t* vals2_out, uint32_t* vals2_tmp) {
+                         const uint32_t* vals2_in, uint32_t* vals2_out, uint32_t* vals2_tmp, bool table_zeroed) {
     if (n <= 0) return GSR_OK;
     const int bits = end_bit - begin_bit;
     const bool v2 = vals2_in != nullptr;
@@ -401,7 +411,7 @@ int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint3
     super_tab[0] = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(group_tot) + gsr_align(size_t(geo.ngroups) * RS_MAX_BINS * 4));
     super_tab[1] = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(super_tab[0]) + super_bytes);
     // the first pass's supergroup table is zeroed here, every later one by the scatter kernel of the pass before it
-    GSR_HIP_CHECK(hipMemsetAsync(super_tab[0], 0, size_t(geo.nsuper) * RS_MAX_BINS * 4, s));
+    if (!table_zeroed) GSR_HIP_CHECK(hipMemsetAsync(super_tab[0], 0, size_t(geo.nsuper) * RS_MAX_BINS * 4, s));
 
     // ping-pong so that the last pass lands in *_out
     const uint32_t* src_k = keys_in; const uint32_t* src_v = vals_in; const uint32_t* src_v2 = vals2_in;
@@ -443,8 +453,10 @@ int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint3
 // Instance count ahead of the depth sort: partial sums of tiles_touched (the host adds <= 256 words), so that the one
 // host round trip of the forward overlaps the depth sort instead of following the scan.
 __global__ void __launch_bounds__(256) count_partials_kernel(const uint32_t* __restrict__ counts, int N, int chunk,
-                                                             unsigned long long* __restrict__ partial) {
+                                                             unsigned long long* __restrict__ partial,
+                                                             uint32_t* __restrict__ zero, int zero_words) {
     __shared__ unsigned long long wt[4];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < zero_words; i += gridDim.x * 256) zero[i] = 0;
     const int begin = blockIdx.x * chunk, end = min(N, begin + chunk);
     unsigned long long sum = 0;     // 64-bit: a scene that overflows the 32-bit instance indices must be SEEN to
     for (int i = begin + threadIdx.x; i < end; i += 256) sum += counts[i];
@@ -455,7 +467,8 @@ __global__ void __launch_bounds__(256) count_partials_kernel(const uint32_t* __r
     if (threadIdx.x == 0) partial[blockIdx.x] = wt[0] + wt[1] + wt[2] + wt[3];
 }
 
-int gsr_launch_count_partials(const uint32_t* counts, int N, unsigned long long* partial, int* n_partial, hipStream_t s) {
+int gsr_launch_count_partials(const uint32_t* counts, int N, unsigned long long* partial, int* n_partial,
+                              uint32_t* zero, size_t zero_words, hipStream_t s) {
     int blocks = (N + 4095) / 4096;
     if (blocks > GSR_COUNT_PARTIALS) blocks = GSR_COUNT_PARTIALS;
     if (blocks < 1) blocks = 1;
@@ -464,29 +477,62 @@ int gsr_launch_count_partials(const uint32_t* counts, int N, unsigned long long*
     if (blocks < 1) blocks = 1;
     *n_partial = blocks;
     GsrProfileScope prof(GSR_K_SCAN, s);
-    hipLaunchKernelGGL(count_partials_kernel, dim3(blocks), dim3(256), 0, s, counts, N, chunk, partial);
+    hipLaunchKernelGGL(count_partials_kernel, dim3(blocks), dim3(256), 0, s, counts, N, chunk, partial, zero, (int)zero_words);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }
 
 // Tile rects in depth-rank order: ONE gather by Gaussian id; the scan of the counts and the emission below then
 // read everything coalesced (before, the scan gathered tiles_touched twice and emit gathered four arrays).
-__global__ void __launch_bounds__(256) rank_gather_kernel(int N, const uint32_t* __restrict__ order,
-                                                          const uint2* __restrict__ tile_rect,
-                                                          uint2* __restrict__ rank_rect,
-                                                          uint32_t* __restrict__ rank_cnt) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= N) return;
-    const uint2 R = tile_rect[order[r]];
-    rank_rect[r] = R;
-    rank_cnt[r] = (R.y & 0xFFFFu) * (R.y >> 16);
+// The same kernel leaves the per-tile sums the scan of the counts starts from (its first launch, fused: a workgroup
+// owns the SCAN_TILE ranks of one scan tile).
+__global__ void __launch_bounds__(SCAN_BLOCK) rank_gather_kernel(int N, const uint32_t* __restrict__ order,
+                                                                 const uint2* __restrict__ tile_rect,
+                                                                 uint2* __restrict__ rank_rect,
+                                                                 uint32_t* __restrict__ rank_cnt,
+                                                                 uint32_t* __restrict__ partial) {
+    __shared__ uint32_t wt[SCAN_BLOCK / 64];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x;
+    uint32_t g[SCAN_ITEMS];
+    uint2 R[SCAN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) g[i] = base + i * SCAN_BLOCK < N ? order[base + i * SCAN_BLOCK] : 0u;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) R[i] = base + i * SCAN_BLOCK < N ? tile_rect[g[i]] : make_uint2(0u, 0u);
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int r = base + i * SCAN_BLOCK;
+        if (r < N) {
+            const uint32_t c = (R[i].y & 0xFFFFu) * (R[i].y >> 16);
+            rank_rect[r] = R[i];
+            rank_cnt[r] = c;
+            sum += c;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
+    if ((threadIdx.x & 63) == 0) wt[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = wt[0] + wt[1] + wt[2] + wt[3];
 }
 
-int gsr_launch_rank_gather(int N, const uint32_t* order, const uint2* tile_rect, uint2* rank_rect, uint32_t* rank_cnt,
-                           hipStream_t s) {
+// rank_rect / rank_cnt in depth-rank order, then offs = exclusive scan of rank_cnt (offs[N] = total); scan_ws as for
+// gsr_exclusive_scan_u32
+int gsr_launch_rank_gather_scan(int N, const uint32_t* order, const uint2* tile_rect, uint2* rank_rect, uint32_t* rank_cnt,
+                                uint32_t* offs, void* scan_ws, hipStream_t s) {
     if (N <= 0) return GSR_OK;
-    GsrProfileScope prof(GSR_K_EMIT, s);
-    hipLaunchKernelGGL(rank_gather_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, order, tile_rect, rank_rect, rank_cnt);
+    uint32_t* partial = static_cast<uint32_t*>(scan_ws);
+    const int blocks = (N + SCAN_TILE - 1) / SCAN_TILE;
+    {
+        GsrProfileScope prof(GSR_K_EMIT, s);
+        hipLaunchKernelGGL(rank_gather_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, s, N, order, tile_rect, rank_rect, rank_cnt, partial);
+    }
+    {
+        GsrProfileScope prof(GSR_K_SCAN, s);
+        hipLaunchKernelGGL(scan_apply_kernel<uint32_t>, dim3(blocks), dim3(SCAN_BLOCK), 0, s, rank_cnt, (const uint32_t*)nullptr,
+                           partial, offs, (int64_t)N);
+    }
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }
@@ -495,13 +541,19 @@ int gsr_launch_rank_gather(int N, const uint32_t* order, const uint2* tile_rect,
 // range.  Lane k parks rank k's (first output index, Gaussian id, tile rect) in LDS; then the 64 lanes fill the
 // range 64 outputs at a time, each finding its owner by binary search over the 64 first-indices -- the two
 // output streams are written fully coalesced however unequal the rects are.
+// (Also clears two small arrays later kernels of the frame need zeroed -- the tile ranges and the tile sort's supergroup
+// table -- instead of a memset launch each.)
 __global__ void __launch_bounds__(256) emit_instances_kernel(int N, int gx,
                                                              const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ offs,
                                                              const uint2* __restrict__ rank_rect,
                                                              uint32_t* __restrict__ tile_keys,
-                                                             uint32_t* __restrict__ emit_gid) {
+                                                             uint32_t* __restrict__ emit_gid,
+                                                             uint32_t* __restrict__ zero_a, int words_a,
+                                                             uint32_t* __restrict__ zero_b, int words_b) {
     __shared__ uint32_t s_off[4][64], s_gid[4][64], s_xy[4][64], s_w[4][64];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < words_a; i += gridDim.x * 256) zero_a[i] = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < words_b; i += gridDim.x * 256) zero_b[i] = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;   // depth rank
     uint32_t off = 0xFFFFFFFFu, g = 0, xy = 0, w = 1;
@@ -534,22 +586,25 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int N, int gx,
 }
 
 int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const uint32_t* offs,
-                    const uint2* rank_rect, uint32_t* tile_keys, uint32_t* emit_gid, hipStream_t s) {
+                    const uint2* rank_rect, uint32_t* tile_keys, uint32_t* emit_gid,
+                    uint32_t* zero_a, size_t words_a, uint32_t* zero_b, size_t words_b, hipStream_t s) {
     if (N <= 0) return GSR_OK;
     (void)grid_y;
     GsrProfileScope prof(GSR_K_EMIT, s);
     hipLaunchKernelGGL(emit_instances_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, grid_x,
-                       order, offs, rank_rect, tile_keys, emit_gid);
+                       order, offs, rank_rect, tile_keys, emit_gid, zero_a, (int)words_a, zero_b, (int)words_b);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }
 
 // Tile ranges from the sorted tile keys (Gaussian id and emission index of every list entry are the tile sort's own two
 // value outputs; the 80-byte records themselves are NOT copied into list order: the render kernels gather them by id).
+// Also clears the per-instance row-count bytes the backward's slot_count fills in (instances nobody walked keep 0).
 __global__ void __launch_bounds__(256) finalize_bins_kernel(int D, const uint32_t* __restrict__ tile_sorted,
-                                                            uint32_t* __restrict__ ranges) {
+                                                            uint32_t* __restrict__ ranges, uint8_t* __restrict__ slot_cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D) return;
+    if (slot_cnt) slot_cnt[i] = 0;
     const uint32_t t = tile_sorted[i];
     const uint32_t tp = i > 0 ? tile_sorted[i - 1] : 0xFFFFFFFFu;
     if (i == 0) ranges[2 * t] = 0;
@@ -557,11 +612,13 @@ __global__ void __launch_bounds__(256) finalize_bins_kernel(int D, const uint32_
     if (i == D - 1) ranges[2 * t + 1] = D;
 }
 
-int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted, uint32_t* ranges, hipStream_t s) {
-    GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
+// `ranges` must already be zero (gsr_launch_emit clears it); `slot_cnt` (may be NULL): D bytes to clear
+int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted, uint32_t* ranges, uint8_t* slot_cnt,
+                             hipStream_t s) {
+    (void)n_tiles;
     if (D <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_FINALIZE, s);
-    hipLaunchKernelGGL(finalize_bins_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, D, tile_keys_sorted, ranges);
+    hipLaunchKernelGGL(finalize_bins_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, D, tile_keys_sorted, ranges, slot_cnt);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

@@ -264,21 +264,28 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         // until the data has arrived.
         unsigned long long* d_host = reinterpret_cast<unsigned long long*>(pinned_counter());
         if (!d_host) { gsr_set_error("hipHostMalloc failed (instance-count read-back buffer)"); return GSR_E_HIP; }
-        unsigned long long* d_partial = static_cast<unsigned long long*>(scan_ws);   // (the scan below overwrites it after the copy)
+        // the kernel stores its few words straight into the pinned slot (device-mapped host memory, visible to the host
+        // once the event behind the kernel has completed): no copy launch in the stream; the same kernel clears the
+        // depth sort's supergroup table
+        void* d_partial = nullptr;
+        GSR_HIP_CHECK(hipHostGetDevicePointer(&d_partial, d_host, 0));
+        uint32_t* zero_n = nullptr; size_t zero_n_words = 0;
+        gsr_sort_zero_region(sort_ws, N, &zero_n, &zero_n_words);
         int n_partial = 0;
-        rc = gsr_launch_count_partials(tiles_touched, N, d_partial, &n_partial, s);
+        rc = gsr_launch_count_partials(tiles_touched, N, static_cast<unsigned long long*>(d_partial), &n_partial,
+                                       zero_n, zero_n_words, s);
         if (rc != GSR_OK) return rc;
         hipEvent_t ev;
         GSR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        hipError_t e1 = hipMemcpyAsync(d_host, d_partial, size_t(n_partial) * 8, hipMemcpyDeviceToHost, s);
-        hipError_t e2 = e1 == hipSuccess ? hipEventRecord(ev, s) : e1;
+        hipError_t e2 = hipEventRecord(ev, s);
         if (e2 == hipSuccess && !defer_color)
             rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, color_jac, s);
         // depth order of the Gaussians (stable; culled ones carry key 0xFFFFFFFF and no tiles)
         if (e2 == hipSuccess && rc == GSR_OK)
-            rc = gsr_radix_sort_pairs(depth_key, nullptr, keys_sorted, order, keys_tmp, vals_tmp, N, 0, 32, sort_ws, s);
-        if (e2 == hipSuccess && rc == GSR_OK) rc = gsr_launch_rank_gather(N, order, tile_rect, rank_rect, rank_cnt, s);
-        if (e2 == hipSuccess && rc == GSR_OK) rc = gsr_exclusive_scan_u32(rank_cnt, nullptr, offs, N, scan_ws, s);
+            rc = gsr_radix_sort_pairs(depth_key, nullptr, keys_sorted, order, keys_tmp, vals_tmp, N, 0, 32, sort_ws, s,
+                                      nullptr, nullptr, nullptr, /*table_zeroed=*/true);
+        if (e2 == hipSuccess && rc == GSR_OK)
+            rc = gsr_launch_rank_gather_scan(N, order, tile_rect, rank_rect, rank_cnt, offs, scan_ws, s);
         hipError_t e3 = e2 == hipSuccess ? hipEventSynchronize(ev) : e2;   // the one host wait of the forward
         (void)hipEventDestroy(ev);
         GSR_HIP_CHECK(e3);
@@ -312,14 +319,18 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         uint32_t* tv_tmp = reinterpret_cast<uint32_t*>(sc2 + 6 * db);
         uint32_t* tg_tmp = reinterpret_cast<uint32_t*>(sc2 + 7 * db);
         void* sort_ws2 = sc2 + 8 * db;
-        rc = gsr_launch_emit(N, gx, gy, order, offs, rank_rect, tile_keys, emit_gid, s);
+        uint32_t* zero_d = nullptr; size_t zero_d_words = 0;
+        gsr_sort_zero_region(sort_ws2, D, &zero_d, &zero_d_words);
+        rc = gsr_launch_emit(N, gx, gy, order, offs, rank_rect, tile_keys, emit_gid, ranges, size_t(n_tiles) * 2,
+                             zero_d, zero_d_words, s);
         if (rc != GSR_OK) return rc;
         // values = emission indices 0..D-1: the sort generates them itself (vals_in = NULL); the Gaussian ids travel as a
         // second value array straight into point_list (no gather through the emission index afterwards)
         rc = gsr_radix_sort_pairs(tile_keys, nullptr, tile_sorted, perm, tk_tmp, tv_tmp, D, 0,
-                                  bits_for((uint32_t)n_tiles), sort_ws2, s, emit_gid, point_list, tg_tmp);
+                                  bits_for((uint32_t)n_tiles), sort_ws2, s, emit_gid, point_list, tg_tmp, /*table_zeroed=*/true);
         if (rc != GSR_OK) return rc;
-        rc = gsr_launch_finalize_bins((int)D, n_tiles, tile_sorted, ranges, s);
+        rc = gsr_launch_finalize_bins((int)D, n_tiles, tile_sorted, ranges,
+                                      fwd_only ? nullptr : at<uint8_t>(binning, BL.slot_cnt), s);
         if (rc != GSR_OK) return rc;
     } else {
         GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
@@ -382,13 +393,13 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     }
     const bool wide = view->channels != 3;
     const size_t row_bytes_each = size_t(GSR_GROW_FLOATS) * 4 + (wide ? size_t(view->channels) * 4 : 0);
-    const size_t cnt_bytes = gsr_align(n_inst * 4);
+    const size_t cnt_bytes = 0;     // (the row-count bytes live in BINNING, cleared by the forward)
     const size_t slot_bytes = gsr_align((n_inst + 1) * 4);
     const size_t scan_bytes = gsr_scan_workspace_bytes((int64_t)n_inst);
     const size_t sums_bytes = gsr_align(size_t(N > 0 ? N : 1) * GSR_GROW_FLOATS * 4);
     char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, cnt_bytes + slot_bytes + scan_bytes + sums_bytes));
     if (!scratch) { gsr_set_error("allocator returned NULL (backward scratch)"); return GSR_E_ALLOC; }
-    uint8_t* slot_cnt = reinterpret_cast<uint8_t*>(scratch);
+    uint8_t* slot_cnt = const_cast<uint8_t*>(at<uint8_t>(binning, BL.slot_cnt));
     uint32_t* slot_off = reinterpret_cast<uint32_t*>(scratch + cnt_bytes);
     void* scan_ws = scratch + cnt_bytes + slot_bytes;
     float* row_sums = reinterpret_cast<float*>(scratch + cnt_bytes + slot_bytes + scan_bytes);
@@ -396,7 +407,6 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     size_t n_rows = n_inst * GSR_SUBROWS;       // the bound
     const uint32_t* touch = at<uint32_t>(binning, BL.touch);
     if (num_rendered > 0) {
-        GSR_HIP_CHECK(hipMemsetAsync(slot_cnt, 0, size_t(num_rendered), s));   // instances nobody walked keep 0 rows
         rc = gsr_launch_slot_count(num_rendered, gx * gy, at<uint32_t>(binning, BL.ranges), at<uint32_t>(binning, BL.covered),
                                    touch, at<uint32_t>(binning, BL.inst_row), slot_cnt, s);
         if (rc != GSR_OK) return rc;

@@ -81,7 +81,7 @@ struct GsrGeomLayout {
     }
 };
 struct GsrBinLayout {
-    size_t point_list, inst_row, ranges, covered, touch, total;
+    size_t point_list, inst_row, ranges, covered, touch, slot_cnt, total;
     GsrBinLayout(int64_t D, int64_t tiles) {
         size_t o = 0;
         point_list = o; o += gsr_align(size_t(D) * 4);
@@ -94,6 +94,9 @@ struct GsrBinLayout {
         // one byte per (sorted instance, quad): did the forward blend it into >= 1 pixel of that quad?
         // The backward evaluates exactly those pairs (everything else has zero gradient).
         touch = o;      o += gsr_align(size_t(D) * 4);
+        // gradient rows per instance (emission order), one byte each: cleared by the forward's last binning kernel,
+        // filled in by the backward's slot_count for the instances somebody walked
+        slot_cnt = o;   o += gsr_align(size_t(D));
         total = o > 0 ? o : 256;
     }
 };
@@ -119,7 +122,10 @@ size_t gsr_sort_ws_bytes(int64_t n);
 int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
                          uint32_t* vals_out, uint32_t* keys_tmp, uint32_t* vals_tmp, int64_t n,
                          int begin_bit, int end_bit, void* ws, hipStream_t s,
-                         const uint32_t* vals2_in = nullptr, uint32_t* vals2_out = nullptr, uint32_t* vals2_tmp = nullptr);
+                         const uint32_t* vals2_in = nullptr, uint32_t* vals2_out = nullptr, uint32_t* vals2_tmp = nullptr,
+                         bool table_zeroed = false);
+// the words of a sort workspace that must be zero when the sort starts (table_zeroed = true: the caller cleared them)
+void gsr_sort_zero_region(void* ws, int64_t n, uint32_t** ptr, size_t* words);
 
 // ---------------------------------------------------------------- kernel launchers
 int gsr_launch_preprocess_fwd(const GsrView& v, const GsrGaussians& g, float* splat,
@@ -131,12 +137,16 @@ int gsr_launch_preprocess_color(const GsrView& v, const GsrGaussians& g, float* 
 bool gsr_color_jac_available(const GsrView& v, const GsrGaussians& g);
 // 64-bit partial sums of counts[0..N) (<= GSR_COUNT_PARTIALS of them, *n_partial says how many): the host adds them up
 #define GSR_COUNT_PARTIALS 256
-int gsr_launch_count_partials(const uint32_t* counts, int N, unsigned long long* partial, int* n_partial, hipStream_t s);
-int gsr_launch_rank_gather(int N, const uint32_t* order, const uint2* tile_rect, uint2* rank_rect, uint32_t* rank_cnt,
-                           hipStream_t s);
+// (`partial` may be device-mapped host memory; `zero`: words this kernel also clears, e.g. gsr_sort_zero_region)
+int gsr_launch_count_partials(const uint32_t* counts, int N, unsigned long long* partial, int* n_partial,
+                              uint32_t* zero, size_t zero_words, hipStream_t s);
+int gsr_launch_rank_gather_scan(int N, const uint32_t* order, const uint2* tile_rect, uint2* rank_rect, uint32_t* rank_cnt,
+                                uint32_t* offs, void* scan_ws, hipStream_t s);
 int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const uint32_t* offs,
-                    const uint2* rank_rect, uint32_t* tile_keys, uint32_t* emit_gid, hipStream_t s);
-int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted, uint32_t* ranges, hipStream_t s);
+                    const uint2* rank_rect, uint32_t* tile_keys, uint32_t* emit_gid,
+                    uint32_t* zero_a, size_t words_a, uint32_t* zero_b, size_t words_b, hipStream_t s);
+int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted, uint32_t* ranges, uint8_t* slot_cnt,
+                             hipStream_t s);
 int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* splat,
                           float* final_T, uint32_t* n_contrib, float* out_color,
                           float* out_allmap, uint8_t* touch, uint32_t* covered, const float* feat, const uint32_t* point_list,
