@@ -72,9 +72,14 @@ def algorithmic_bytes(N, D, P):
     }
 
 
-def iteration_bytes(N, D, P, tiles):
+def iteration_bytes(N, D, P, tiles, D_walked=None):
+    """Whole-iteration algorithmic bytes.  `D_walked`: charge the compositing kernels only the instances
+    they can have touched (the binning sorts all D either way)."""
     npass = math.ceil((32 + math.ceil(math.log2(max(tiles, 2)))) / 8)
     b = algorithmic_bytes(N, D, P)
+    if D_walked is not None:
+        bw = algorithmic_bytes(N, D_walked, P)
+        b["render_fwd"], b["render_bwd"] = bw["render_fwd"], bw["render_bwd"]
     return sum(b.values()) + D * 12 * (1 + 2 * npass) + N * 58 * 28
 
 
@@ -119,7 +124,12 @@ def pmc_traffic(kernel):
     return int(FETCH_FACTOR[cls] * k["fetch_kb"] * 1024 + k["write_kb"] * 1024), raw
 
 
-VALU_CEILING_GINST_S = 922.0   # measured: scripts/microbench/valu_rate.hip, independent wave64 v_fma_f32, whole chip
+# measured (round 3): scripts/microbench/valu_rate.hip, independent wave64 v_fma_f32 as inline assembly, 8 waves per SIMD,
+# whole chip: 764 G wave-instructions/s (3.2 cycles per instruction and SIMD at 2.4 GHz); compare + select and DPP adds
+# 536 G/s, v_rcp_f32 273 G/s.  SQ_INSTS_VALU reads 1.001x the known instruction count of those loops
+# (profiles/r03_valu_calib.json; scripts/valu_calib.sh).  Round 2 quoted 922: its loop had been SLP-packed into
+# v_pk_fma_f32 and the packed rate was counted twice.
+VALU_CEILING_GINST_S = 764.0
 
 
 def pmc_valu_insts(kernel):
@@ -297,6 +307,13 @@ def main():
         # (same box, 200 steps, three alternating runs each: 470.4 / 474.9 / 477.3 vs 482.9 / 483.2 / 478.8 it/s).
         vp = ViewParallel(model, overlap_local=True)
 
+    # how many ranks the collective backend itself sees (an all-reduce of ones), for the top level of the JSON line
+    ranks_counted = None
+    if dist.is_initialized():
+        ones = torch.ones(1, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_counted = int(ones.item())
+
     base_iter = 10_000
     # the view of the next step is known (this rank always renders its own view): the SH optimiser step leaves its colours
     # (gsr_adam_sh_factored_next), the next forward skips the SH colour pass.  GSR_BENCH_COLOR_CACHE=0: off (A/B aid)
@@ -447,10 +464,15 @@ def main():
         D, P = dbg["num_rendered"], W * H
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         nc = dbg["n_contrib"][0].float()
+        # what K6 / K7 actually walk: per tile the longest prefix of its list any quad staged before its pixels saturated
+        # (the contractual byte model charges all D instances; on occluded scenes most of them are never touched)
+        D_walked = int(dbg["covered"].long().max(dim=1).values.sum()) if dbg["covered"].numel() else 0
         per_kernel = {k: (ms / n if n else 0.0) for k, (ms, n) in prof.items() if k in big and n}
         dom = max(per_kernel, key=per_kernel.get)
         ab = algorithmic_bytes(N, D, P)
         achieved = ab[dom] / (per_kernel[dom] * 1e-3) / 1e9 if per_kernel[dom] > 0 else 0.0
+        ab_walked = algorithmic_bytes(N, D_walked, P)
+        achieved_walked = ab_walked[dom] / (per_kernel[dom] * 1e-3) / 1e9 if per_kernel[dom] > 0 else 0.0
         ms_per_step = elapsed / args.steps * 1e3
         iter_b = iteration_bytes(N, D, P, tiles)
         traffic, traffic_raw = pmc_traffic(dom) if headline else (None, None)    # the committed counters are this workload's
@@ -476,13 +498,19 @@ def main():
                          "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, same scene): "
                                            "fetch_factor x FETCH_SIZE + WRITE_SIZE, factor per read class calibrated on known "
                                            "byte counts (profiles/r02_fetch_calib.json, scripts/microbench/fetch_calib.hip)",
-                         "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per_kernel[dom]},
+                         "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per_kernel[dom],
+                         # the same fraction with D_walked = sum over tiles of the longest staged prefix instead of D: the
+                         # bytes the compositing kernels can have moved (equal to `frac` unless lists are occluded)
+                         "walked": {"instances_walked": D_walked, "algorithmic_bytes_per_launch": ab_walked[dom],
+                                    "achieved": achieved_walked, "frac": achieved_walked / HBM_PEAK_GBS}},
             # the dominant kernels are VALU-bound: the same launch priced against the MEASURED
             # vector-issue ceiling of the chip instead of the HBM roofline (informational, not the contract's roofline)
             "valu_issue": (lambda n: None if not n or per_kernel[dom] <= 0 else {
                 "kernel": dom, "valu_wave_insts_per_launch": n, "achieved_ginst_s": n / (per_kernel[dom] * 1e-3) / 1e9,
                 "ceiling_ginst_s": VALU_CEILING_GINST_S, "frac": n / (per_kernel[dom] * 1e-3) / 1e9 / VALU_CEILING_GINST_S,
-                "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU); ceiling: scripts/microbench/valu_rate.hip"})(
+                "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU, calibrated 1.001x on known counts); ceiling: independent "
+                          "v_fma_f32, scripts/microbench/valu_rate.hip + profiles/r03_valu_calib.json -- a kernel's mix also "
+                          "holds 4.6-cycle (compare, select, DPP) and 9-cycle (rcp, exp) instructions"})(
                     pmc_valu_insts(dom) if headline else None),
             "hbm_peak_gb": {"allocated": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
                             "reserved": round(torch.cuda.max_memory_reserved(dev) / 2**30, 2)},
@@ -491,8 +519,13 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in per_kernel.items()},
             "kernel_ms_warmup": {k: round(v, 4) for k, v in warm.items()},
             "kernel_ms_per_step": {k: round(ms / args.steps, 4) for k, (ms, n) in prof.items() if n},
-            "iteration": {"algorithmic_bytes": iter_b, "hbm_frac": iter_b / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "iteration": {"algorithmic_bytes": iter_b, "hbm_frac": iter_b / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "hbm_frac_walked": iteration_bytes(N, D, P, tiles, D_walked) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        # top level, so that "did RCCL see N ranks, and which step ran" needs no digging in a scaling record
+        out["comm_backend"] = dist.get_backend() if dist.is_initialized() else None
+        out["comm_ranks_counted"] = ranks_counted          # all-reduce of ones over that backend (None: single process)
+        out["view_parallel_path"] = dp_path                # "pipelined" / "blocking" / fallback note (None: single GPU)
         if vp is not None and (world > 1 or force_dp):
             out["view_parallel"] = {"path": dp_path, "comm_exposed_ms_per_step": comm_exposed_ms,
                                     "collective_waits_per_step": comm_waits,

@@ -24,6 +24,7 @@ struct PreBwdParams {
     float mod;
     const float* view; const float* proj; const float* campos;
     bool raw;
+    bool aabb_grad_cutoff1;   // GSR_FLAG_AABB_GRAD_CUTOFF1
     bool factored;      // GSR_FLAG_FACTORED_SH_GRAD: masked colour gradient out, no SH gradient arrays
     const float* means; const float* shs; const float* shs_rest; const float* opac; const float* scales; const float* rots;
     const float* tprecomp;
@@ -196,9 +197,11 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
 
         // ---- 3a. AABB centre -> T -----------------------------------------------------------
         if (dxy0 != 0.f || dxy1 != 0.f) {
-            const float t[3] = {GSR_CUTOFF * GSR_CUTOFF, GSR_CUTOFF * GSR_CUTOFF, -1.0f};
+            // (GSR_FLAG_AABB_GRAD_CUTOFF1: the recalled variant that chains this gradient with weights (1, 1, -1))
+            const float cc = p.aabb_grad_cutoff1 ? 1.0f : GSR_CUTOFF * GSR_CUTOFF;
+            const float t[3] = {cc, cc, -1.0f};
             const float d = t[0] * Tw[0] * Tw[0] + t[1] * Tw[1] * Tw[1] + t[2] * Tw[2] * Tw[2];
-            const float inv_d = 1.0f / d;
+            const float inv_d = d != 0.0f ? 1.0f / d : 0.0f;
             float dL_dd = 0.f;
             float dTw_add[3];
 #pragma unroll
@@ -422,6 +425,7 @@ int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int
     p.N = g.count; p.W = v.width; p.H = v.height; p.deg = v.sh_degree; p.M = v.sh_coeffs;
     p.mod = v.scale_modifier; p.view = v.viewmatrix; p.proj = v.projmatrix; p.campos = v.campos;
     p.raw = (v.flags & (uint32_t)GSR_FLAG_RAW_PARAMS) != 0;
+    p.aabb_grad_cutoff1 = (v.flags & (uint32_t)GSR_FLAG_AABB_GRAD_CUTOFF1) != 0;
     p.factored = (v.flags & (uint32_t)GSR_FLAG_FACTORED_SH_GRAD) != 0 && g.shs != nullptr;
     if (p.factored && !out.dL_dcolors) { gsr_set_error("GSR_FLAG_FACTORED_SH_GRAD needs dL_dcolors"); return GSR_E_INVALID; }
     p.means = g.means3D; p.shs = g.shs; p.shs_rest = g.shs_rest; p.opac = g.opacities; p.scales = g.scales; p.rots = g.rotations;

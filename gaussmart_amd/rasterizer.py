@@ -678,7 +678,7 @@ def rasterize_debug(means3D, opacities, shs=None, colors_precomp=None, scales=No
                             ("tiles_touched", torch.int32, (N,)), ("depth_key", torch.int32, (N,)),
                             ("order", torch.int32, (N,)), ("offs", torch.int32, (N + 1,))],
         _lib.GSR_BUF_BINNING: [("point_list", torch.int32, (D,)), ("inst_row", torch.int32, (D,)),
-                               ("ranges", torch.int32, (-1, 2))],
+                               ("ranges", torch.int32, (-1, 2)), ("covered", torch.int32, (-1, 4))],
         _lib.GSR_BUF_IMAGE: [("final_T", torch.float32, (3, H, W)), ("n_contrib", torch.int32, (2, H, W))],
     }
     for which, fields in spec.items():

@@ -53,6 +53,11 @@ enum {
     GSR_FLAG_CLAMP_PASSTHROUGH = 1, /* gradient flows through alpha = min(0.99, o*G) when clamped */
     GSR_FLAG_FILTER_DEPTH_GRAD = 2, /* low-pass branch: dL/dz also added to dL/dTw.x,.y times s   */
     GSR_FLAGS_UPSTREAM = 3,
+    GSR_FLAG_AABB_GRAD_CUTOFF1 = 512, /* third recalled non-derivative (a reviewer's recollection of upstream backward.cu, as
+                                       unverifiable here as the two above): the gradient of the screen-space centre
+                                       (dL/dmean2D of the low-pass branch -> T) is chained with the weights (1, 1, -1)
+                                       although the forward's centre uses (cutoff^2, cutoff^2, -1) = (9, 9, -1).  Not
+                                       part of GSR_FLAGS_UPSTREAM; kernels and oracle implement both settings */
     GSR_FLAG_DEBUG_NO_CULL = 4,     /* test aid: ignore the per-wave cull rect (results are bit-identical) */
     GSR_FLAG_DEBUG_RECT_CULL_ONLY = 64, /* test / measurement aid: cull with the rect only, skip the ellipse test (same results) */
     GSR_FLAG_DEFER_COLOR = 16,      /* enqueue the SH colour pass as LATE as possible -- after binning, right before the

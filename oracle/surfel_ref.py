@@ -47,6 +47,7 @@ AABB_MIN_EXTENT2 = 1e-4
 QUIRK_CLAMP_PASSTHROUGH = 1   # d(min(0.99, o*G)) treated as identity even when clamped
 QUIRK_FILTER_DEPTH_GRAD = 2   # low-pass branch: dL/dz also flows to Tw.x, Tw.y scaled by s
 QUIRKS_UPSTREAM = QUIRK_CLAMP_PASSTHROUGH | QUIRK_FILTER_DEPTH_GRAD
+QUIRK_AABB_GRAD_CUTOFF1 = 512  # screen-space centre: forward value with weights (9, 9, -1), gradient of the (1, 1, -1) form
 
 SH_C0 = 0.28209479177387814
 SH_C1 = 0.4886025119029199
@@ -138,8 +139,9 @@ class Geom(NamedTuple):
 
 
 def preprocess(means3D, scales, rotations, opacities, shs, colors_precomp, transmat_precomp,
-               S: Settings) -> Geom:
-    """[U] preprocess: cull, T matrix, AABB, tile rect, normal, SH colour."""
+               S: Settings, flags: int = 0) -> Geom:
+    """[U] preprocess: cull, T matrix, AABB, tile rect, normal, SH colour.  `flags`: only QUIRK_AABB_GRAD_CUTOFF1 matters
+    here (the centre keeps its forward VALUE, its gradient is the one of the weights (1, 1, -1))."""
     N = means3D.shape[0]
     dt = means3D.dtype
     V = S.viewmatrix.to(dt)
@@ -191,6 +193,13 @@ def preprocess(means3D, scales, rotations, opacities, shs, colors_precomp, trans
     rad_f = torch.maximum(torch.maximum(hx, hy), torch.tensor(CUTOFF * FILTER_SIZE, dtype=dt))
     radius = torch.ceil(rad_f)
     xy = torch.stack([cx, cy], -1)
+    if flags & QUIRK_AABB_GRAD_CUTOFF1:
+        t1 = torch.tensor([1.0, 1.0, -1.0], dtype=dt)
+        d1 = (t1 * Tw * Tw).sum(-1)
+        d1safe = torch.where(d1.detach() != 0, d1, torch.ones_like(d1))
+        f1 = torch.where((d1.detach() != 0)[:, None], t1[None, :] / d1safe[:, None], torch.zeros_like(f))
+        xy1 = torch.stack([(f1 * Tu * Tw).sum(-1), (f1 * Tv * Tw).sum(-1)], -1)
+        xy = xy1 + (xy - xy1).detach()
 
     cxd, cyd = cx.detach(), cy.detach()
     def tdiv(v):  # (int)(v / TILE): truncation toward zero, like the C cast
@@ -508,7 +517,7 @@ class _OracleRasterize(torch.autograd.Function):
         with torch.enable_grad():
             geom = preprocess(leaves["means3D"], leaves["scales"], leaves["rotations"],
                               leaves["opacities"], leaves["shs"], leaves["colors_precomp"],
-                              leaves["cov3D_precomp"], S)
+                              leaves["cov3D_precomp"], S, flags)
             rgb_v = geom.rgb if geom.rgb is not None else leaves["colors_precomp"][geom.vis_idx]
             opa_v = leaves["opacities"][geom.vis_idx, 0]
         dt = means3D.dtype

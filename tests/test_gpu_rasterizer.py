@@ -177,8 +177,10 @@ def _grad_compare(a, cam, dev, flags, bg=(0.2, 0.4, 0.6), colors=None, cov=None,
     return stats, (c.detach().cpu(), oc)
 
 
-@pytest.mark.parametrize("flags", [3, 0])
+@pytest.mark.parametrize("flags", [3, 0, 3 | 512, 512])
 def test_backward_parity_sh_scale_rot(gpu_device, flags):
+    # 512 = GSR_FLAG_AABB_GRAD_CUTOFF1, the third recalled non-derivative (include/gsr.h): both settings, with and
+    # without the other two quirks, against the oracle taking the same flags
     p, cam = facing_scene(2000, 256, 256, seed=0)
     stats, _ = _grad_compare(activate(p), cam, gpu_device, flags)
     for k, s in stats.items():
@@ -201,6 +203,34 @@ def test_backward_parity_degree_modifier_and_view(gpu_device, deg, scale_modifie
         # same median / p99 bars as above; the single worst element is a pair whose fp32 and fp64 threshold decisions
         # differ and depends on the scene: 1e-3 ... 3.3e-3 over these four
         assert s["normwise"] < 5e-3 and s["median"] < 1e-4 and s["p99"] < 2e-3, (k, s)
+
+
+def test_aabb_gradient_quirk_changes_the_centre_chain_only(gpu_device):
+    """GSR_FLAG_AABB_GRAD_CUTOFF1 (recalled, unverifiable: DESIGN.md section 2) rescales how dL/d(screen-space centre) --
+    the low-pass branch's gradient -- reaches T: sub-pixel splats, where that branch is taken, must see a different
+    geometry gradient under the flag, colours and opacities must not, and each setting must match the oracle."""
+    p, cam = facing_scene(1500, 128, 128, seed=2)
+    p = dict(p)
+    p["scaling"] = p["scaling"] - 2.5          # log-scales: splats of well under a pixel -> rho2d < rho3d nearly everywhere
+    a = activate(p)
+    s_on, _ = _grad_compare(a, cam, gpu_device, 3 | 512)
+    s_off, _ = _grad_compare(a, cam, gpu_device, 3)
+    for stats in (s_on, s_off):
+        for k, st in stats.items():
+            assert st["normwise"] < 2e-3 and st["median"] < 1e-4, (k, st)
+    from diff_surfel_rasterization import GaussianRasterizer
+    grads = {}
+    for flags in (3, 3 | 512):
+        t = {k: v.clone().to(gpu_device).requires_grad_(True) for k, v in a.items()}
+        rast = GaussianRasterizer(hip_settings(cam, 3, (0.2, 0.4, 0.6), gpu_device), flags=flags)
+        c, _, am = rast(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"], requires_grad=True), shs=t["shs"],
+                        opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+        (c.square().sum() + am[0].sum()).backward()
+        grads[flags] = {k: v.grad.detach().cpu() for k, v in t.items()}
+    # the effect is small by construction: the two weightings differ in the x / y components of f = t / d, which multiply
+    # Tw.x, Tw.y -- second order for the small splats that take the low-pass branch at all (measured: 7e-4 of the scale)
+    assert float((grads[3]["means3D"] - grads[3 | 512]["means3D"]).abs().max()) > 1e-4 * float(grads[3]["means3D"].abs().max())
+    assert torch.equal(grads[3]["shs"], grads[3 | 512]["shs"]) and torch.equal(grads[3]["opacities"], grads[3 | 512]["opacities"])
 
 
 def test_backward_parity_random_orientations(gpu_device):

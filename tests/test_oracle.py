@@ -137,3 +137,31 @@ def test_means2d_grad_is_densification_statistic():
     assert torch.all(m2d.grad[:, 2] == 0)
     assert torch.all(m2d.grad[radii == 0] == 0)
     assert m2d.grad[radii > 0].abs().sum() > 0
+
+
+def test_aabb_centre_quirk_keeps_the_forward_value():
+    """QUIRK_AABB_GRAD_CUTOFF1 (third recalled non-derivative, include/gsr.h GSR_FLAG_AABB_GRAD_CUTOFF1): the screen-space
+    centre keeps the value of the (9, 9, -1) weights; only its gradient is the one of the (1, 1, -1) form, which is the
+    exact derivative of THAT form (checked against autograd of the form itself)."""
+    a, cam = _inputs(200, 64, 64, 1, torch.float64)
+    S = oracle_settings(cam, 3, torch.float64)
+    g0 = O.preprocess(a["means3D"], a["scales"], a["rotations"], a["opacities"], a["shs"], None, None, S)
+    leaves = {k: a[k].detach().clone().requires_grad_(True) for k in ("means3D", "scales", "rotations")}
+    g1 = O.preprocess(leaves["means3D"], leaves["scales"], leaves["rotations"], a["opacities"], a["shs"], None, None, S,
+                      O.QUIRK_AABB_GRAD_CUTOFF1)
+    assert torch.equal(g0.xy, g1.xy.detach()) and torch.equal(g0.radii, g1.radii)
+    w = torch.randn_like(g1.xy)
+    grads = torch.autograd.grad((g1.xy * w).sum(), list(leaves.values()))
+    # the (1, 1, -1) form written out on the same T rows
+    leaves2 = {k: a[k].detach().clone().requires_grad_(True) for k in ("means3D", "scales", "rotations")}
+    g2 = O.preprocess(leaves2["means3D"], leaves2["scales"], leaves2["rotations"], a["opacities"], a["shs"], None, None, S)
+    Tu, Tv, Tw = g2.Tm[:, 0], g2.Tm[:, 1], g2.Tm[:, 2]
+    t1 = torch.tensor([1.0, 1.0, -1.0], dtype=torch.float64)
+    f1 = t1 / (t1 * Tw * Tw).sum(-1, keepdim=True)
+    xy1 = torch.stack([(f1 * Tu * Tw).sum(-1), (f1 * Tv * Tw).sum(-1)], -1)
+    ref = torch.autograd.grad((xy1 * w).sum(), list(leaves2.values()), retain_graph=True)
+    for x, y in zip(grads, ref):
+        assert torch.allclose(x, y, rtol=1e-10, atol=1e-12)
+    # and it is NOT the derivative of the forward's own centre
+    own = torch.autograd.grad((g2.xy * w).sum(), list(leaves2.values()))
+    assert any(float((x - y).abs().max()) > 1e-9 for x, y in zip(grads, own))
