@@ -217,6 +217,62 @@ def cpu_baseline(params, cam, n_tiles_sample, n_gauss_sample, dbg, W, H, full=Fa
                       f"{t_pre * ns / N + t_bin + t_tiles + t_loss + t_adam:.1f} s"}
 
 
+def wide_payload_bench(args, preset, N, W, H, radius_px):
+    """BASELINE.json config 5 ("extra per-Gaussian feature channels rendered / backpropped"; build-defined: SURVEY section 0
+    fact 5): the operator with colors_precomp [N,C] -- forward + backward through the C-ABI, per-kernel times from the
+    library's event profiler, peak HBM.  One "iteration" = one forward + one backward of the rasterizer (no loss kernels,
+    no optimiser: the reference has no C-channel training loop to time).  One GPU."""
+    import torch as _t
+    from gaussmart_amd import _lib
+    from gaussmart_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussmart_amd.synthetic import activate, make_scene
+    C = args.channels
+    dev = _t.device("cuda:0")
+    _lib.lib()
+    log(f"wide payload: {N} Gaussians, {W}x{H}, radius {radius_px} px, {C} channels")
+    params, cam = make_scene(N, W, H, seed=0, device="cpu", radius_px=radius_px)
+    a = {k: v.to(dev) for k, v in activate(params).items() if k in ("means3D", "opacities", "scales", "rotations")}
+    g = _t.Generator().manual_seed(0)
+    col = _t.rand(N, C, generator=g).to(dev).requires_grad_(True)
+    ins = {k: a[k].clone().requires_grad_(True) for k in a}
+    rs = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), _t.zeros(C, device=dev), 1.0,
+                                       cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), 3,
+                                       cam.camera_center.to(dev), False, False)
+    rast = GaussianRasterizer(rs)
+    wc, wa = _t.randn(C, H, W, device=dev), _t.randn(7, H, W, device=dev)
+    m2d = _t.zeros(N, 3, device=dev, requires_grad=True)
+
+    def step():
+        c, r, am = rast(means3D=ins["means3D"], means2D=m2d, colors_precomp=col, opacities=ins["opacities"],
+                        scales=ins["scales"], rotations=ins["rotations"])
+        ((c * wc).sum() + (am * wa).sum()).backward()
+        for t in (col, m2d, *ins.values()):
+            t.grad = None
+    for _ in range(max(args.warmup, 2)):
+        step()
+    _t.cuda.synchronize()
+    _t.cuda.reset_peak_memory_stats(dev)
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _t.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    prof = {k: round(ms / max(n, 1), 4) for k, (ms, n) in _lib.profile_read().items() if n}
+    out = {"metric": f"rasterizer fwd+bwd iters/sec @{N} Gaussians {W}x{H}, {C}-channel payload", "value": args.steps / elapsed,
+           "unit": "iters/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": elapsed / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{preset['what']}; colors_precomp [{N},{C}] through GaussianRasterizer forward + backward "
+                                  f"(event-timed per kernel, so the wall figure carries ~5 us per bracket)",
+                      "preset": args.preset, "gaussians": N, "width": W, "height": H, "radius_px": radius_px, "channels": C},
+           "kernel_ms": prof,
+           "hbm_peak_gb": {"allocated": round(_t.cuda.max_memory_allocated(dev) / 2**30, 2),
+                           "reserved": round(_t.cuda.max_memory_reserved(dev) / 2**30, 2)}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,12 +288,17 @@ def main():
     ap.add_argument("--cpu-gaussians", type=int, default=250_000)
     ap.add_argument("--cpu-full", action="store_true", help="CPU baseline on the whole frame, un-sampled (~2 min)")
     ap.add_argument("--forward-frames", type=int, default=50, help="inference frames (no_grad render) timed after the run")
+    ap.add_argument("--channels", type=int, default=3,
+                    help="wide per-pixel payload (BASELINE.json config 5): time the operator's forward + backward with "
+                         "colors_precomp [N,C], C = 4..64 (multiple of 4), on the chosen preset instead of the training step")
     args = ap.parse_args()
     preset = PRESETS[args.preset]
     N = args.gaussians or preset["gaussians"]
     W, H = args.width or preset["width"], args.height or preset["height"]
     radius_px = args.radius_px if args.radius_px is not None else preset["radius_px"]
     headline = (N, W, H, radius_px) == (1_000_000, 1920, 1080, 6.0)
+    if args.channels != 3:
+        return wide_payload_bench(args, preset, N, W, H, radius_px)
 
     # Rank 0 must print exactly ONE line on stdout, but RCCL writes a version banner to fd 1 when the first
     # communicator is created: park the real stdout and send everything else (library chatter included) to stderr.

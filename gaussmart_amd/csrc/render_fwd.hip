@@ -44,6 +44,9 @@ extern "C" int gsr_probe_read_stamps(void* dst, size_t bytes) {
 #endif
 #define RF_BLOCK 256
 #define RF_WAVES 4
+#ifndef RF_PFD
+#define RF_PFD 2   // wide payload: how many surviving entries ahead their features are fetched
+#endif
 
 struct RenderFwdParams {
     int W, H, gx, n_tiles, per_xcd;
@@ -67,27 +70,31 @@ __device__ __forceinline__ uint32_t row_or_step(uint32_t v) {
 }
 
 // FEAT16 = 0: three colour channels taken from the splat record (the reference's configuration).
-// FEAT16 = 1..4: up to 16*FEAT16 feature channels read from `feat` [N,C] by Gaussian id, staged per batch in a
-// wave-private LDS tile (wide per-pixel payload); everything else is identical.
+// FEAT16 = 1..4: up to 16*FEAT16 feature channels read from `feat` [N,C] by Gaussian id (wide per-pixel
+// payload); everything else is identical.  The feature accumulate C[pixel][ch] += w[pixel] * f[ch] is an outer product
+// per surviving entry, and it runs on the MATRIX pipe: v_mfma_f32_16x16x1_4b_f32 (exact f32, one fma per product, k-ordered:
+// bit-identical to the scalar fmaf chain it replaces) takes B = the lane's own blending weight -- block b of the
+// instruction is DPP row b = 4x4 pixel block b, column j = lane & 15 = the lane's own pixel, so the weights need no
+// cross-lane movement at all -- and A = the entry's features, 16 lanes x FEAT16 consecutive floats read straight from the
+// feature row with a scalar base (row i of M-tile m is channel FEAT16 * i + m).  One instruction per 16 channels and
+// entry, issued for every entry that survives the quad cull with weight 0 on the lanes that do not blend it; the VALU only
+// sees FEAT16 more issue slots per pair instead of C fused multiply-adds behind a per-splat feature fetch (round 2:
+// C = 64 ran at 3.8 ms load-latency-bound, C = 16 at 0.86 ms).  Features are prefetched two surviving entries ahead.
 // SAVE = false: forward-only rendering (render.py / view.py under torch.no_grad(); utils/mesh_utils.py:100-123): no
 // touch bytes, no per-pixel state for a backward that will never run -- the mask bookkeeping, four DPP OR steps and
 // eight readlanes per batch and 20 of the 60 bytes written per pixel disappear.
 // PROBE (developer builds only: make PROBES=1, scripts/dev_probe.py): 1 = eight more dependent VALU per splat, 4 = eight
 // more dependent SALU, 2 = no distortion arithmetic, 3 = four LDS reads instead of five, 5 = no reciprocal in the depth
 // mapping.  Probes 2, 3 and 5 render WRONG images: they exist to time the loop (DESIGN.md section 4 holds what they showed).
+// leaving a pair early: the RGB kernel goes straight to the next entry; the wide kernel still owes the entry its MFMA
+// (a plain block, NOT do { } while (0): `continue` must reach the loop over the surviving entries)
+#define RF_NEXT_PAIR { if (FEAT16 > 0) goto pair_done; else continue; }
 template <int FEAT16, bool SAVE, int PROBE = 0>
-__global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : 2) render_fwd_kernel(RenderFwdParams p) {
+__global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : (FEAT16 == 1 ? 5 : FEAT16 == 2 ? 4 : 3)) render_fwd_kernel(RenderFwdParams p) {
     __shared__ float4 s_rec_all[RF_WAVES][64 * 5];
-    // wide payload: the features of the staged entries that survive the cull, [entry][channel], wave-private
-    // (up to 32 channels: 8 KiB per wave; wider payloads would cut the occupancy to one wave per SIMD and read the
-    // features with wave-uniform scalar loads instead)
-    constexpr bool STAGE_FEAT = FEAT16 == 1 || FEAT16 == 2;
-    __shared__ float4 s_feat_all[STAGE_FEAT ? RF_WAVES : 1][STAGE_FEAT ? 64 * 4 * FEAT16 : 1];
-
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     float4* s_rec = s_rec_all[wave];
-    float4* s_feat = s_feat_all[STAGE_FEAT ? wave : 0];
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b
     // takes tile (b % 8) * per_xcd + b / 8 -- every XCD owns one contiguous band of tiles, and the records shared by
     // neighbouring tiles are fetched into ONE L2 instead of several
@@ -117,10 +124,15 @@ __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : 2) rend
     float T = 1.0f;
     uint32_t last_contributor = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    constexpr int NF = FEAT16 > 0 ? 16 * FEAT16 : 1;
-    float Cf[NF];
+    // wide payload: FEAT16 accumulator tiles of the 4-block outer-product MFMA; register v of lane l holds
+    // (pixel 16 (v >> 2) + (l & 15), channel FEAT16 * (4 (l >> 4) + (v & 3)) + m) of tile m
+    constexpr int NM = FEAT16 > 0 ? FEAT16 : 1;
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc[NM];
 #pragma unroll
-    for (int k = 0; k < NF; ++k) Cf[k] = 0.f;
+    for (int k = 0; k < NM; ++k)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[k][v] = 0.f;
     float N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float Dacc = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med_depth = 0.f;
     uint32_t med_contrib = 0xFFFFFFFFu;   // "-1" stored in the u32 plane, as recalled
@@ -144,7 +156,7 @@ __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : 2) rend
                              (!tight_cull || gsr_tight_overlaps_quad(pf0, pf1, pf2, pf3.z, qx0, qy0)));
 s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_rec[lane * 5 + 3] = pf3; s_rec[lane * 5 + 4] = pf4;
         const uint32_t id_of_lane = ids_cur;
-        if (!STAGE_FEAT) {   // prefetch the next batch while this one is composited
+        {   // prefetch the next batch while this one is composited
             const int nxt = base + 64;
             const int cnt_nxt = nxt < n_list ? min(64, n_list - nxt) : 0;
             GSR_GATHER5(ids_nxt, cnt_nxt);
@@ -155,27 +167,25 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
         __builtin_amdgcn_wave_barrier();
 
         unsigned long long m = __ballot(ov);
-        if (STAGE_FEAT) {
-            // wide payload: lane l fetches the C features of staged entry l (if it survived the cull) and parks them in
-            // LDS; the loads are issued BEFORE the next batch's record prefetch, so waiting for them does not wait for it
-            constexpr int NQ = STAGE_FEAT ? 4 * FEAT16 : 1;
-            float4 ft[NQ];
-            const float4* fsrc = reinterpret_cast<const float4*>(p.feat + (size_t)id_of_lane * p.C);
+        // wide payload: A operands (features) of the next RF_PFD surviving entries, fetched ahead of their use
+        float fq[RF_PFD][NM];
+        unsigned long long mq = m;
+        auto fetch_features = [&](float (&f)[NM]) {
 #pragma unroll
-            for (int k = 0; k < NQ; ++k)
-                if (ov && 4 * k < p.C) ft[k] = fsrc[k];
-            {
-                const int nxt = base + 64;
-                const int cnt_nxt = nxt < n_list ? min(64, n_list - nxt) : 0;
-                GSR_GATHER5(ids_nxt, cnt_nxt);
-                ids_cur = ids_nxt;
-                ids_nxt = nxt + 64 + lane < n_list ? p.point_list[r0 + nxt + 64 + lane] : 0u;
+            for (int e = 0; e < NM; ++e) f[e] = 0.f;
+            if (FEAT16 > 0 && mq) {                          // wave-uniform
+                const int jn = __builtin_ctzll(mq);
+                mq &= mq - 1;
+                const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id_of_lane, jn);   // scalar
+                const float* src = p.feat + (size_t)gid * p.C + NM * l16;
+#pragma unroll
+                for (int e = 0; e < NM; ++e)
+                    if (NM * l16 + e < p.C) f[e] = src[e];
             }
+        };
+        if (FEAT16 > 0) {
 #pragma unroll
-            for (int k = 0; k < NQ; ++k)
-                if (ov && 4 * k < p.C) s_feat[lane * NQ + k] = ft[k];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            for (int d = 0; d < RF_PFD; ++d) fetch_features(fq[d]);
         }
         uint32_t mine_lo = 0u, mine_hi = 0u;   // staged splats THIS pixel blends (bit j)
         float probe_v = pxf; uint32_t probe_s = (uint32_t)__builtin_amdgcn_readfirstlane(nb);
@@ -188,7 +198,19 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
 #pragma unroll
                 for (int q = 0; q < 8; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(probe_s) : : "scc");
             }
-            if (done) continue;
+            float w_pair = 0.f;     // this lane's blending weight of entry j (0: not blended) -- the MFMA's B operand
+            float fc[NM];
+            if (FEAT16 > 0) {
+#pragma unroll
+                for (int e = 0; e < NM; ++e) {
+                    fc[e] = fq[0][e];
+#pragma unroll
+                    for (int d = 0; d + 1 < RF_PFD; ++d) fq[d][e] = fq[d + 1][e];
+                }
+                fetch_features(fq[RF_PFD - 1]);
+            }
+            {
+            if (done) RF_NEXT_PAIR;
             const uint32_t contributor = (uint32_t)(base + j + 1);   // 1-based position in the tile list
             const float4 a0 = s_rec[j * 5 + 0], a1 = s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
             const float4 a3 = s_rec[j * 5 + 3];
@@ -197,10 +219,10 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
                 for (int q = 0; q < 8; ++q) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(probe_v));
             }
             GsrPair pr;
-            if (!gsr_pair_eval(pxf, pyf, a0, a1, a2, a3.z, pr)) continue;
+            if (!gsr_pair_eval(pxf, pyf, a0, a1, a2, a3.z, pr)) RF_NEXT_PAIR;
             const float alpha = pr.alpha, depth = pr.depth;
             const float test_T = T * (1.0f - alpha);
-            if (test_T < GSR_T_EPS) { done = true; continue; }
+            if (test_T < GSR_T_EPS) { done = true; RF_NEXT_PAIR; }
             const float4 a4 = PROBE == 3 ? a3 : s_rec[j * 5 + 4];
             const float w = alpha * T;
             const float A = 1.0f - T;
@@ -214,25 +236,19 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
             Dacc += depth * w;
             if (T > 0.5f) { med_depth = depth; med_contrib = contributor; }
             N0 += a2.w * w; N1 += a3.x * w; N2 += a3.y * w;
-            if (FEAT16 == 0) {
-                C0 += a3.w * w; C1 += a4.x * w; C2 += a4.y * w;
-            } else {
-                const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id_of_lane, j);   // wave-uniform
-                const float4* f = STAGE_FEAT ? s_feat + j * (4 * FEAT16)       // LDS broadcast
-                                             : reinterpret_cast<const float4*>(p.feat + (size_t)gid * p.C);
-#pragma unroll
-                for (int k = 0; k < NF / 4; ++k) {
-                    if (4 * k < p.C) {
-                        const float4 v = f[k];
-                        Cf[4 * k] += v.x * w; Cf[4 * k + 1] += v.y * w; Cf[4 * k + 2] += v.z * w; Cf[4 * k + 3] += v.w * w;
-                    }
-                }
-            }
+            if (FEAT16 == 0) { C0 += a3.w * w; C1 += a4.x * w; C2 += a4.y * w; }
+            else w_pair = w;
             T = test_T;
             if (SAVE) {
                 last_contributor = contributor;
                 const unsigned long long bit = 1ull << j;          // wave-uniform (scalar shift)
                 mine_lo |= (uint32_t)bit; mine_hi |= (uint32_t)(bit >> 32);
+            }
+            }
+        pair_done:
+            if (FEAT16 > 0) {   // every lane is active again: outer product of this entry's features with the 64 weights
+#pragma unroll
+                for (int k = 0; k < NM; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x1f32(fc[k], w_pair, acc[k], 0, 0, 0);
             }
         }
         if (PROBE == 1) C0 += probe_v * 1e-30f;
@@ -278,10 +294,6 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
             p.out_color[pix_id] = C0 + T * p.bg[0];
             p.out_color[pix_id + HW] = C1 + T * p.bg[1];
             p.out_color[pix_id + 2 * HW] = C2 + T * p.bg[2];
-        } else {
-#pragma unroll
-            for (int k = 0; k < NF; ++k)
-                if (k < p.C) p.out_color[pix_id + (size_t)k * HW] = Cf[k] + T * p.bg[k];
         }
         p.out_allmap[pix_id + 0 * HW] = Dacc;
         p.out_allmap[pix_id + 1 * HW] = 1.0f - T;
@@ -290,6 +302,31 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
         p.out_allmap[pix_id + 4 * HW] = N2;
         p.out_allmap[pix_id + 5 * HW] = med_depth;
         p.out_allmap[pix_id + 6 * HW] = dist;
+    }
+    if (FEAT16 > 0) {   // the accumulator tiles hold (pixel of block b, channel) pairs of OTHER lanes' pixels: see `acc`
+        float bgv[NM][4];
+#pragma unroll
+        for (int k = 0; k < NM; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = NM * (4 * grp + r) + k;
+                bgv[k][r] = ch < p.C ? p.bg[ch] : 0.f;
+            }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float Tb = __shfl(T, 16 * b + l16, 64);
+            const int pxb = qx0 + (b & 1) * 4 + (l16 & 3), pyb = qy0 + (b >> 1) * 4 + (l16 >> 2);
+            if (pxb < p.W && pyb < p.H) {
+                const size_t pidb = (size_t)pyb * p.W + pxb;
+#pragma unroll
+                for (int k = 0; k < NM; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ch = NM * (4 * grp + r) + k;
+                        if (ch < p.C) p.out_color[pidb + (size_t)ch * HW] = acc[k][4 * b + r] + Tb * bgv[k][r];
+                    }
+            }
+        }
     }
 #ifdef GSR_DEV_PROBES
     if (PROBE == 7) {
