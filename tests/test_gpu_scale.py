@@ -109,3 +109,57 @@ def test_training_converges_on_multi_view_synthetic(gpu_device):
     train(m, cams, opt, pipe, bg, cameras_extent=5.0, first_iter=7000, iterations=7300)
     after = mean_psnr()
     assert math.isfinite(after) and after > before + 3.0, (before, after)
+
+
+@pytest.mark.parametrize("channels", [16, 64])
+def test_wide_payload_at_the_bicycle_shape(gpu_device, channels):
+    """BASELINE.json config 5 at its own shape (5 M Gaussians @1237x822, D = 22.6 M instances, exact-row path) with a wide
+    per-Gaussian payload through forward + backward: finite, bitwise deterministic, zero gradient for culled Gaussians, and
+    the peak memory follows the MEASURED row count (~2.6 D rows of (80 + 4 C) bytes), not the 16 D bound.  The config is
+    build-defined (the reference's --lambda_dino never widens the rasterizer payload,
+    utils/loss_utils.py:82-84); parity of the wide kernels against the oracle is tests/test_gpu_wide_payload.py."""
+    import gc
+    from conftest import hip_settings
+    from gaussmart_amd.rasterizer import GaussianRasterizer, release_workspace
+    from gaussmart_amd.synthetic import make_scene, jittered_cameras, activate
+    dev = gpu_device
+    n, w, h, radius_px = 5_000_000, 1237, 822, 9.0
+    params, _ = make_scene(n, w, h, seed=0, radius_px=radius_px)
+    cam = jittered_cameras(2, w, h, seed=0, device=dev)[1]
+    a = {k: v.to(dev) for k, v in activate(params).items() if k in ("means3D", "opacities", "scales", "rotations")}
+    del params
+    g = torch.Generator().manual_seed(channels)
+    col = torch.rand(n, channels, generator=g).to(dev)
+    wc = torch.randn(channels, 1, 1, generator=g).to(dev)          # one weight per channel: no C x H x W weight image
+    rast = GaussianRasterizer(hip_settings(cam, 3, tuple([0.0] * channels), dev))
+
+    def run():
+        ins = {k: a[k].clone().requires_grad_(True) for k in a}
+        c_in = col.clone().requires_grad_(True)
+        m2d = torch.zeros(n, 3, device=dev, requires_grad=True)
+        c, r, am = rast(means3D=ins["means3D"], means2D=m2d, colors_precomp=c_in, opacities=ins["opacities"],
+                        scales=ins["scales"], rotations=ins["rotations"])
+        ((c * wc).sum() * 1e-3 + am[0].mean() + am[1].mean()).backward()
+        torch.cuda.synchronize()
+        out = (c.detach().sum(dim=(1, 2)), am.detach().clone(), r, c_in.grad, ins["means3D"].grad, ins["opacities"].grad)
+        del c, am
+        return out
+
+    gc.collect(); release_workspace(); torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
+    base = torch.cuda.memory_allocated(dev)
+    s1, am1, r1, gc1, gm1, go1 = run()
+    peak = (torch.cuda.max_memory_allocated(dev) - base) / 2**30
+    D_bound_gib = 16 * 22.6e6 * (80 + 4 * channels) / 2**30
+    print(f"\n[bicycle-like, C = {channels}] peak HBM over forward + backward above the inputs: {peak:.2f} GiB "
+          f"(the 16 D row bound would be {D_bound_gib:.0f} GiB)")
+    # rows ~2.6 D x (80 + 4 C) B, the [C,H,W] image and its gradient, the N x C feature gradient, binning, scratch
+    assert peak < (6.0 if channels == 16 else 12.0), peak       # measured 4.1 / 8.6 GiB
+    assert torch.isfinite(s1).all() and torch.isfinite(am1).all() and torch.isfinite(gc1).all() and torch.isfinite(gm1).all()
+    vis = r1 > 0
+    assert 0.5 * n < int(vis.sum()) <= n
+    assert float(gc1[~vis].abs().max()) == 0.0 and float(gm1[~vis].abs().max()) == 0.0
+    assert float(gc1.abs().max()) > 0.0 and float(am1[1].mean()) > 0.3
+    s2, am2, r2, gc2, gm2, go2 = run()
+    assert torch.equal(s1, s2) and torch.equal(am1, am2) and torch.equal(r1, r2)
+    assert torch.equal(gc1, gc2) and torch.equal(gm1, gm2) and torch.equal(go1, go2)
