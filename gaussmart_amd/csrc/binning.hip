@@ -153,6 +153,9 @@ int gsr_exclusive_scan_u8(const uint8_t* in, uint32_t* out, int64_t n, void* ws,
 #define RS_TILE (RS_BLOCK * RS_ITEMS)
 #define RS_MAX_BINS 256
 #define RS_SUPER 32          // groups per supergroup
+#ifndef RS_RB
+#define RS_RB 16             // table rows a scatter workgroup has in flight at a time (registers against round trips)
+#endif
 #define RS_MAX_G 32          // tiles per group at most (one LDS histogram per tile of the group: 32 KB)
 #define RS_GROUPS_TARGET 512 // => at most 16 supergroups (ONE batch of row loads per scatter workgroup) up to 33 M pairs
 
@@ -270,22 +273,24 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_scatter_kernel(const uint32_t* __
         if (tid < NB) {
             const int g = (int)blockIdx.x / G, sg = g / RS_SUPER, g0 = sg * RS_SUPER;
             const uint32_t pre = tile_pre[(size_t)blockIdx.x * NB + tid];
-            uint32_t gv[RS_SUPER - 1];
+            for (int q0 = 0; q0 < nsuper; q0 += RS_RB) {
+                uint32_t sv[RS_RB];
 #pragma unroll
-            for (int k = 0; k < RS_SUPER - 1; ++k) gv[k] = group_tot[(size_t)min(g0 + k, g) * NB + tid];
-            for (int q0 = 0; q0 < nsuper; q0 += 16) {
-                uint32_t sv[16];
+                for (int k = 0; k < RS_RB; ++k) sv[k] = super_tot[(size_t)min(q0 + k, nsuper - 1) * NB + tid];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) sv[k] = super_tot[(size_t)min(q0 + k, nsuper - 1) * NB + tid];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
+                for (int k = 0; k < RS_RB; ++k) {
                     const uint32_t v = q0 + k < nsuper ? sv[k] : 0u;
                     tot += v;
                     before += q0 + k < sg ? v : 0u;
                 }
             }
+            for (int k0 = 0; g0 + k0 < g; k0 += RS_RB) {      // (wave-uniform trip count)
+                uint32_t gv[RS_RB];
 #pragma unroll
-            for (int k = 0; k < RS_SUPER - 1; ++k) before += g0 + k < g ? gv[k] : 0u;
+                for (int k = 0; k < RS_RB; ++k) gv[k] = group_tot[(size_t)min(g0 + k0 + k, g) * NB + tid];
+#pragma unroll
+                for (int k = 0; k < RS_RB; ++k) before += g0 + k0 + k < g ? gv[k] : 0u;
+            }
             before += pre;
         }
         uint32_t tot_unused;

@@ -143,18 +143,23 @@ static int validate(const GsrView* v, const GsrGaussians* g) {
     return GSR_OK;
 }
 
-// 2 KiB of pinned host memory per calling thread, for the one device -> host read of gsr_forward (the partial sums of
-// the instance count); allocated on first use and kept (a forward is synchronous with respect to this read, so one slot
-// per thread suffices).
-static uint32_t* pinned_counter() {
-    thread_local uint32_t* slot = nullptr;   // (8-byte aligned: also read as 64-bit words)
-    if (!slot) {
+// Pinned host memory per calling thread, for the one device -> host read of gsr_forward (the partial sums of the
+// instance count, one 64-bit word per workgroup of the geometry pass): allocated on first use, grown when a call needs
+// more, kept otherwise (a forward is synchronous with respect to this read, so one buffer per thread suffices).
+static unsigned long long* pinned_words(size_t words) {
+    thread_local unsigned long long* buf = nullptr;
+    thread_local size_t cap = 0;
+    if (words > cap) {
+        if (buf) (void)hipHostFree(buf);
+        buf = nullptr; cap = 0;
+        size_t want = words < 256 ? 256 : words + words / 4;
         void* p = nullptr;
-        if (hipHostMalloc(&p, GSR_COUNT_PARTIALS * 8, hipHostMallocDefault) != hipSuccess) return nullptr;
-        slot = static_cast<uint32_t*>(p);
+        if (hipHostMalloc(&p, want * 8, hipHostMallocDefault) != hipSuccess) return nullptr;
+        buf = static_cast<unsigned long long*>(p); cap = want;
     }
-    return slot;
+    return buf;
 }
+static uint32_t* pinned_counter() { return reinterpret_cast<uint32_t*>(pinned_words(1)); }
 
 // above this many bytes of worst-case gradient rows the backward reads the exact row count back (one host wait)
 static size_t exact_rows_threshold() {
@@ -239,8 +244,36 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     } color_join{s, nullptr, false};
     uint32_t D = 0;
     if (N > 0) {
-        rc = gsr_launch_preprocess_fwd(*view, *g, splat, clamped, tiles_touched, tile_rect, depth_key, out->radii, s);
+        // The instance count D = sum of tiles_touched sizes the next buffers, so the host has to see it.  It does not
+        // depend on the depth order: the geometry pass leaves one partial sum per workgroup straight in pinned host
+        // memory (device-mapped: no copy launch in the stream) and the depth sort, the rank gather and the scan are enqueued
+        // BEHIND the event that marks its end -- the host round trip (wait, add the partials up, allocate, launch) is over
+        // long before they are, so the stream never drains.  (Rounds 1-2 read the scan's total back with nothing but the
+        // colour pass behind it: with the colour pass on another stream the main stream idled for the round trip.)  The
+        // same launch clears the depth sort's supergroup table.  Above 8 M Gaussians a small counting kernel produces
+        // <= 256 partials instead (the host would add up tens of thousands).
+        const int pre_blocks = gsr_preprocess_fwd_blocks(N);
+        const bool fused_count = pre_blocks <= 32768;
+        int n_partial = fused_count ? pre_blocks : GSR_COUNT_PARTIALS;
+        unsigned long long* d_host = pinned_words((size_t)n_partial);
+        if (!d_host) { gsr_set_error("hipHostMalloc failed (instance-count read-back buffer)"); return GSR_E_HIP; }
+        void* d_partial = nullptr;
+        GSR_HIP_CHECK(hipHostGetDevicePointer(&d_partial, d_host, 0));
+        uint32_t* zero_n = nullptr; size_t zero_n_words = 0;
+        gsr_sort_zero_region(sort_ws, N, &zero_n, &zero_n_words);
+        rc = gsr_launch_preprocess_fwd(*view, *g, splat, clamped, tiles_touched, tile_rect, depth_key, out->radii,
+                                       fused_count ? static_cast<unsigned long long*>(d_partial) : nullptr,
+                                       fused_count ? zero_n : nullptr, fused_count ? zero_n_words : 0, s);
         if (rc != GSR_OK) return rc;
+        if (!fused_count) {
+            rc = gsr_launch_count_partials(tiles_touched, N, static_cast<unsigned long long*>(d_partial), &n_partial,
+                                           zero_n, zero_n_words, s);
+            if (rc != GSR_OK) return rc;
+        }
+        struct EventGuard { hipEvent_t e = nullptr; ~EventGuard() { if (e) (void)hipEventDestroy(e); } } evg;
+        GSR_HIP_CHECK(hipEventCreateWithFlags(&evg.e, hipEventDisableTiming));
+        hipEvent_t ev = evg.e;
+        hipError_t e2 = hipEventRecord(ev, s);
         if (defer_color) {
             hipStream_t cs = static_cast<hipStream_t>(alloc(ctx, GSR_BUF_COLOR_STREAM, 0));
             if (cs && cs != s) {
@@ -254,30 +287,6 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
                 color_join.done = ev2[1]; color_join.armed = true;
             }
         }
-        // The instance count D = sum of tiles_touched sizes the next buffers, so the host has to see it.  It does not
-        // depend on the depth order: partial sums are taken right behind the geometry pass and copied out, and the
-        // depth sort, the rank gather and the scan are enqueued BEHIND that copy -- the host round trip (wait on the
-        // event, allocate, launch) is over long before they are, so the stream never drains.  (Rounds 1-2 read the
-        // scan's total back, with nothing but the colour pass behind it: with the colour pass on another stream the
-        // main stream idled for the round trip.)
-        // The destination must be PINNED: a copy into pageable memory blocks the host inside hipMemcpyAsync
-        // until the data has arrived.
-        unsigned long long* d_host = reinterpret_cast<unsigned long long*>(pinned_counter());
-        if (!d_host) { gsr_set_error("hipHostMalloc failed (instance-count read-back buffer)"); return GSR_E_HIP; }
-        // the kernel stores its few words straight into the pinned slot (device-mapped host memory, visible to the host
-        // once the event behind the kernel has completed): no copy launch in the stream; the same kernel clears the
-        // depth sort's supergroup table
-        void* d_partial = nullptr;
-        GSR_HIP_CHECK(hipHostGetDevicePointer(&d_partial, d_host, 0));
-        uint32_t* zero_n = nullptr; size_t zero_n_words = 0;
-        gsr_sort_zero_region(sort_ws, N, &zero_n, &zero_n_words);
-        int n_partial = 0;
-        rc = gsr_launch_count_partials(tiles_touched, N, static_cast<unsigned long long*>(d_partial), &n_partial,
-                                       zero_n, zero_n_words, s);
-        if (rc != GSR_OK) return rc;
-        hipEvent_t ev;
-        GSR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        hipError_t e2 = hipEventRecord(ev, s);
         if (e2 == hipSuccess && !defer_color)
             rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, color_jac, s);
         // depth order of the Gaussians (stable; culled ones carry key 0xFFFFFFFF and no tiles)
@@ -287,7 +296,6 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         if (e2 == hipSuccess && rc == GSR_OK)
             rc = gsr_launch_rank_gather_scan(N, order, tile_rect, rank_rect, rank_cnt, offs, scan_ws, s);
         hipError_t e3 = e2 == hipSuccess ? hipEventSynchronize(ev) : e2;   // the one host wait of the forward
-        (void)hipEventDestroy(ev);
         GSR_HIP_CHECK(e3);
         if (rc != GSR_OK) return rc;
         uint64_t total = 0;

@@ -128,9 +128,13 @@ int gsr_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, uint3
 void gsr_sort_zero_region(void* ws, int64_t n, uint32_t** ptr, size_t* words);
 
 // ---------------------------------------------------------------- kernel launchers
+// `count_partial` (may be NULL; may be device-mapped host memory): one 64-bit sum of tiles_touched per workgroup,
+// gsr_preprocess_fwd_blocks(N) of them; `zero`: words the launch also clears (e.g. gsr_sort_zero_region)
+int gsr_preprocess_fwd_blocks(int N);
 int gsr_launch_preprocess_fwd(const GsrView& v, const GsrGaussians& g, float* splat,
                               uint32_t* clamped, uint32_t* tiles_touched, uint2* tile_rect, uint32_t* depth_key,
-                              int32_t* radii, hipStream_t s);
+                              int32_t* radii, unsigned long long* count_partial, uint32_t* zero, size_t zero_words,
+                              hipStream_t s);
 int gsr_launch_preprocess_color(const GsrView& v, const GsrGaussians& g, float* splat, uint32_t* clamped,
                                 int32_t* radii, float* color_jac /* [N,9] or NULL */, hipStream_t s);
 // does the colour pass of this call leave d(rgb)/d(dir) (forward and backward must agree)?

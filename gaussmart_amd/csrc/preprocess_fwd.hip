@@ -26,6 +26,9 @@ struct PreParams {
     const float* scales; const float* rots; const float* tprecomp;
     float* splat; uint32_t* clamped; uint32_t* tiles; uint2* rect; uint32_t* dkey; int32_t* radii;
     float* jac;      // colour pass: d(rgb)/d(dir) [N,9] (row c = channel, column a = x, y, z), or NULL
+    // geometry pass: per-workgroup sums of tiles_touched (64-bit; may be device-mapped host memory) or NULL, and a few
+    // words this launch clears for a later kernel (the depth sort's supergroup table)
+    unsigned long long* count_partial; uint32_t* zero; int zero_words;
 };
 
 __device__ __forceinline__ float3 sh_to_rgb(int deg, const float* sh /*[M][3] in LDS or global*/,
@@ -66,24 +69,10 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, const float* sh /*[M][3] in
 // WITH_SH: evaluate the SH colour in this kernel (single-launch form).  The library normally runs
 // the geometry part first and the colour part (preprocess_color_kernel) later, so that the colour
 // evaluation overlaps the host round trip that fetches the instance count.
+// One Gaussian of the geometry pass; returns the number of tiles it touches (0: culled).
 template <bool STAGE_SH, bool WITH_SH>
-__global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int idx = blockIdx.x * PRE_BLOCK + tid;
-    const int wave_first = blockIdx.x * PRE_BLOCK + wave * 64;
-
-    float* my_sh = nullptr;
-    if (STAGE_SH && WITH_SH) {
-        // cooperative, fully coalesced fetch of this wave's 64 SH blocks (wave-private LDS region:
-        // LDS ops of one wave complete in order, no workgroup barrier needed)
-        float* wl = lds + wave * 64 * SH_ROW_FLOATS;
-        sh_stage<true>(wl, const_cast<float*>(p.shs), const_cast<float*>(p.shs_rest), p.M, wave_first,
-                       min(64, p.N - wave_first), lane);
-        my_sh = wl + lane * SH_ROW_FLOATS;
-    }
-    if (idx >= p.N) return;
+__device__ __forceinline__ uint32_t preprocess_one(const PreParams& p, const int idx, const float* my_sh) {
+    if (idx >= p.N) return 0u;
 
     // defaults for a culled Gaussian
     p.radii[idx] = 0;
@@ -97,7 +86,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
     const float vx = px * V[0] + py * V[4] + pz * V[8] + V[12];
     const float vy = px * V[1] + py * V[5] + pz * V[9] + V[13];
     const float vz = px * V[2] + py * V[6] + pz * V[10] + V[14];
-    if (!(vz > GSR_NEAR_N)) return;
+    if (!(vz > GSR_NEAR_N)) return 0u;
 
     float Tu[3], Tv[3], Tw[3], nrm[3];
     if (p.tprecomp == nullptr) {
@@ -138,14 +127,14 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
     }
 
     const float cosv = -(vx * nrm[0] + vy * nrm[1] + vz * nrm[2]);
-    if (cosv == 0.0f) return;
+    if (cosv == 0.0f) return 0u;
     const float sgn = cosv > 0.0f ? 1.0f : -1.0f;
     nrm[0] *= sgn; nrm[1] *= sgn; nrm[2] *= sgn;
 
     // AABB of the 3-sigma ellipse under the homography
     const float t0 = GSR_CUTOFF * GSR_CUTOFF, t1 = GSR_CUTOFF * GSR_CUTOFF, t2 = -1.0f;
     const float d = t0 * Tw[0] * Tw[0] + t1 * Tw[1] * Tw[1] + t2 * Tw[2] * Tw[2];
-    if (d == 0.0f) return;
+    if (d == 0.0f) return 0u;
     const float inv_d = 1.0f / d;
     const float f0 = t0 * inv_d, f1 = t1 * inv_d, f2 = t2 * inv_d;
     const float cx = f0 * Tu[0] * Tw[0] + f1 * Tu[1] * Tw[1] + f2 * Tu[2] * Tw[2];
@@ -155,12 +144,12 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
     const float ex = sqrtf(fmaxf(GSR_AABB_MIN_EXT2, h0x));
     const float ey = sqrtf(fmaxf(GSR_AABB_MIN_EXT2, h0y));
     const float radius = ceilf(fmaxf(fmaxf(ex, ey), GSR_CUTOFF * GSR_FILTER_SIZE));
-    if (!(isfinite(cx) && isfinite(cy) && isfinite(radius))) return;
+    if (!(isfinite(cx) && isfinite(cy) && isfinite(radius))) return 0u;
 
     int x0, y0, x1, y1;
     gsr_tile_rect(cx, cy, (int)radius, p.gx, p.gy, x0, y0, x1, y1);
     const int ntiles = (x1 - x0) * (y1 - y0);
-    if (ntiles == 0) return;
+    if (ntiles == 0) return 0u;
 
     uint32_t clamp_bits = 0;
     float3 rgb = make_float3(0.f, 0.f, 0.f);
@@ -224,7 +213,41 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) 
     p.tiles[idx] = (uint32_t)ntiles;
     if (p.rect) p.rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16));
     p.dkey[idx] = __float_as_uint(vz);
+    return (uint32_t)ntiles;
 }
+
+template <bool STAGE_SH, bool WITH_SH>
+__global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(PreParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ unsigned long long s_cnt[PRE_BLOCK / 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int idx = blockIdx.x * PRE_BLOCK + tid;
+    const int wave_first = blockIdx.x * PRE_BLOCK + wave * 64;
+    for (int i = blockIdx.x * PRE_BLOCK + tid; i < p.zero_words; i += gridDim.x * PRE_BLOCK) p.zero[i] = 0;
+
+    float* my_sh = nullptr;
+    if (STAGE_SH && WITH_SH) {
+        // cooperative, fully coalesced fetch of this wave's 64 SH blocks (wave-private LDS region:
+        // LDS ops of one wave complete in order, no workgroup barrier needed)
+        float* wl = lds + wave * 64 * SH_ROW_FLOATS;
+        sh_stage<true>(wl, const_cast<float*>(p.shs), const_cast<float*>(p.shs_rest), p.M, wave_first,
+                       min(64, p.N - wave_first), lane);
+        my_sh = wl + lane * SH_ROW_FLOATS;
+    }
+    const uint32_t ntiles = preprocess_one<STAGE_SH, WITH_SH>(p, idx, my_sh);
+    // instance count of the frame: one 64-bit partial sum per workgroup, added up by the host (gsr_forward reads it back
+    // while the depth sort runs) -- no separate counting launch
+    if (p.count_partial) {
+        unsigned long long sum = ntiles;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
+        if (lane == 0) s_cnt[wave] = sum;
+        __syncthreads();
+        if (tid == 0) p.count_partial[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    }
+}
+
 
 // Colour part of K1: SH -> RGB (+0.5, clamp at 0, clamp mask) for the Gaussians that survived the
 // culls, written into their splat record.  Runs after the binning front end has been enqueued.
@@ -371,6 +394,7 @@ static void fill_pre_params(PreParams& p, const GsrView& v, const GsrGaussians& 
     p.scales = g.scales; p.rots = g.rotations; p.tprecomp = g.transmat_precomp;
     p.splat = splat; p.clamped = clamped; p.tiles = tiles_touched; p.rect = tile_rect; p.dkey = depth_key; p.radii = radii;
     p.jac = nullptr;
+    p.count_partial = nullptr; p.zero = nullptr; p.zero_words = 0;
 }
 
 bool gsr_color_jac_available(const GsrView& v, const GsrGaussians& g) {
@@ -423,12 +447,16 @@ int gsr_launch_preprocess_color(const GsrView& v, const GsrGaussians& g, float* 
 }
 
 // Geometry part of K1 (everything except the SH colour; precomputed colours are copied here).
+int gsr_preprocess_fwd_blocks(int N) { return (N + PRE_BLOCK - 1) / PRE_BLOCK; }
+
 int gsr_launch_preprocess_fwd(const GsrView& v, const GsrGaussians& g, float* splat,
                               uint32_t* clamped, uint32_t* tiles_touched, uint2* tile_rect, uint32_t* depth_key,
-                              int32_t* radii, hipStream_t s) {
+                              int32_t* radii, unsigned long long* count_partial, uint32_t* zero, size_t zero_words,
+                              hipStream_t s) {
     if (g.count <= 0) return GSR_OK;
     PreParams p;
     fill_pre_params(p, v, g, splat, clamped, tiles_touched, tile_rect, depth_key, radii);
+    p.count_partial = count_partial; p.zero = zero; p.zero_words = (int)zero_words;
     const int blocks = (g.count + PRE_BLOCK - 1) / PRE_BLOCK;
     GsrProfileScope prof(GSR_K_PREPROCESS_FWD, s);
     hipLaunchKernelGGL((preprocess_fwd_kernel<false, false>), dim3(blocks), dim3(PRE_BLOCK), 0, s, p);
