@@ -202,9 +202,11 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     const int n_tiles = gx * gy;
     const int64_t P = (int64_t)W * H;
 
-    const GsrGeomLayout GL(N);
-    const GsrImageLayout IL(P);
     const bool fwd_only = (view->flags & (uint32_t)GSR_FLAG_FORWARD_ONLY) != 0 && view->channels == 3;
+    // (the colour pass leaves d(rgb)/d(dir) in GEOM only for a backward that has no colour cache to take it from)
+    const bool geom_jac = !fwd_only && (view->flags & (uint32_t)GSR_FLAG_COLOR_CACHED) == 0;
+    const GsrGeomLayout GL(N, geom_jac);
+    const GsrImageLayout IL(P);
     void* geom = alloc(ctx, GSR_BUF_GEOM, GL.total);
     void* image = fwd_only ? nullptr : alloc(ctx, GSR_BUF_IMAGE, IL.total);
     if (!geom || (!image && !fwd_only)) { gsr_set_error("allocator returned NULL (geom/image)"); return GSR_E_ALLOC; }
@@ -215,7 +217,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     uint32_t* tiles_touched = at<uint32_t>(geom, GL.tiles_touched);
     uint2* tile_rect = at<uint2>(geom, GL.tile_rect);
     uint32_t* depth_key = at<uint32_t>(geom, GL.depth_key);
-    float* color_jac = fwd_only ? nullptr : at<float>(geom, GL.color_jac);   // (only a backward reads it)
+    float* color_jac = geom_jac ? at<float>(geom, GL.color_jac) : nullptr;   // (only a backward without a colour cache reads it)
 
     // N-sized scratch: depth-sort double buffers, sort + scan workspaces
     const size_t nb = gsr_align(size_t(N > 0 ? N : 1) * 4);
@@ -306,7 +308,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     if (D > 0x7FFFFFF0u) { gsr_set_error("instance count %u overflows", D); return GSR_E_UNSUPPORTED; }
     out->num_rendered = (int32_t)D;
 
-    const GsrBinLayout BL(D, n_tiles);
+    const GsrBinLayout BL(D, n_tiles, !fwd_only);
     void* binning = alloc(ctx, GSR_BUF_BINNING, BL.total);
     if (!binning) { gsr_set_error("allocator returned NULL (binning)"); return GSR_E_ALLOC; }
     out->binning = binning;
@@ -385,7 +387,7 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     hipStream_t s = static_cast<hipStream_t>(stream_);
     const int N = g->count, W = view->width, H = view->height;
     const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
-    const GsrGeomLayout GL(N);
+    const GsrGeomLayout GL(N, (view->flags & (uint32_t)GSR_FLAG_COLOR_CACHED) == 0);   // as the forward laid it out
     const GsrBinLayout BL(num_rendered, gx * gy);
     const GsrImageLayout IL((int64_t)W * H);
 

@@ -65,7 +65,9 @@ static inline size_t gsr_align(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct GsrGeomLayout {
     size_t splat, clamped, tiles_touched, tile_rect, depth_key, order, offs, color_jac, total;
-    explicit GsrGeomLayout(int64_t N) {
+    // with_jac = false (forward-only calls, and calls whose colour comes from a cache that carries the Jacobian itself):
+    // the last region is not reserved -- 36 B per Gaussian nobody would read or write.  The other offsets do not move.
+    explicit GsrGeomLayout(int64_t N, bool with_jac = true) {
         size_t o = 0;
         splat = o;         o += gsr_align(size_t(N) * GSR_SPLAT_FLOATS * 4);
         clamped = o;       o += gsr_align(size_t(N) * 4);
@@ -76,13 +78,15 @@ struct GsrGeomLayout {
         offs = o;          o += gsr_align(size_t(N + 1) * 4);    // depth rank -> first instance (emission order)
         // d(rgb)/d(view direction), 3x3 per Gaussian, left by the SH colour pass so that preprocess_bwd does not have to
         // read the 192 bytes of SH coefficients again for the view-direction term of dL/dmean
-        color_jac = o;     o += gsr_align(size_t(N) * 9 * 4);
+        color_jac = o;     o += with_jac ? gsr_align(size_t(N) * 9 * 4) : 0;
         total = o > 0 ? o : 256;
     }
 };
 struct GsrBinLayout {
     size_t point_list, inst_row, ranges, covered, touch, slot_cnt, total;
-    GsrBinLayout(int64_t D, int64_t tiles) {
+    // keep_for_backward = false (GSR_FLAG_FORWARD_ONLY): the touch words and the row-count bytes -- the two last regions,
+    // 5 B per instance -- are not reserved (the forward-only kernels write neither)
+    GsrBinLayout(int64_t D, int64_t tiles, bool keep_for_backward = true) {
         size_t o = 0;
         point_list = o; o += gsr_align(size_t(D) * 4);
         inst_row = o;   o += gsr_align(size_t(D) * 4);
@@ -93,10 +97,10 @@ struct GsrBinLayout {
         covered = o;    o += gsr_align(size_t(tiles) * 16);
         // one byte per (sorted instance, quad): did the forward blend it into >= 1 pixel of that quad?
         // The backward evaluates exactly those pairs (everything else has zero gradient).
-        touch = o;      o += gsr_align(size_t(D) * 4);
+        touch = o;      o += keep_for_backward ? gsr_align(size_t(D) * 4) : 0;
         // gradient rows per instance (emission order), one byte each: cleared by the forward's last binning kernel,
         // filled in by the backward's slot_count for the instances somebody walked
-        slot_cnt = o;   o += gsr_align(size_t(D));
+        slot_cnt = o;   o += keep_for_backward ? gsr_align(size_t(D)) : 0;
         total = o > 0 ? o : 256;
     }
 };
