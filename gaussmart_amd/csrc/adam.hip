@@ -7,7 +7,6 @@
 // momentum, exactly as with the reference's optimiser.
 // Pure HBM streaming: 16 B read + 12 B written per parameter (1.62 GB at 1M Gaussians).
 #include "gsr_common.h"
-#include <cstdlib>
 #include "sh_basis.h"
 
 #define AD_BLOCK 256
@@ -177,12 +176,6 @@ __device__ __forceinline__ void adam_sh_segment(float* wl, int col0, int row_f, 
     }
 }
 
-// Dynamic LDS claimed beyond the kernel's own tile (GSR_ADAM_SH_LDS_PAD bytes, read once; default below).
-static size_t adam_sh_lds_pad() {
-    static const size_t pad = [] { const char* e = getenv("GSR_ADAM_SH_LDS_PAD"); return e && *e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0; }();
-    return pad;
-}
-
 // NEXT: after the update the wave evaluates, from the new coefficients still in its tile, the SH colour of the NEXT view
 // for its 64 Gaussians -- rgb (+0.5, clamped at 0), the clamp mask and d(rgb)/d(dir) -- into the colour cache the next
 // forward / backward read (GSR_FLAG_COLOR_CACHED): the 192 bytes per Gaussian the colour pass would read again are already
@@ -309,10 +302,8 @@ static int adam_sh_factored_impl(int32_t first, int32_t count, int32_t sh_coeffs
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GsrProfileScope prof(GSR_K_ADAM, s);
     const unsigned blocks = (unsigned)((count + AS_BLOCK - 1) / AS_BLOCK);
-    // LDS the launch claims on top of its 49 KiB tile (see adam_sh_lds_pad)
-    const size_t pad = adam_sh_lds_pad();
-    if (color_cache) hipLaunchKernelGGL(adam_sh_factored_kernel<true>, dim3(blocks), dim3(AS_BLOCK), pad, s, a);
-    else hipLaunchKernelGGL(adam_sh_factored_kernel<false>, dim3(blocks), dim3(AS_BLOCK), pad, s, a);
+    if (color_cache) hipLaunchKernelGGL(adam_sh_factored_kernel<true>, dim3(blocks), dim3(AS_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(adam_sh_factored_kernel<false>, dim3(blocks), dim3(AS_BLOCK), 0, s, a);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }
