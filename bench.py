@@ -527,7 +527,7 @@ def main():
         nc = dbg["n_contrib"][0].float()
         # what K6 / K7 actually walk: per tile the longest prefix of its list any quad staged before its pixels saturated
         # (the contractual byte model charges all D instances; on occluded scenes most of them are never touched)
-        D_walked = int(dbg["covered"].long().max(dim=1).values.sum()) if dbg["covered"].numel() else 0
+        D_walked = int(dbg["covered"].long().max(dim=1).values.sum()) if "covered" in dbg and dbg["covered"].numel() else D
         per_kernel = {k: (ms / n if n else 0.0) for k, (ms, n) in prof.items() if k in big and n}
         dom = max(per_kernel, key=per_kernel.get)
         ab = algorithmic_bytes(N, D, P)

@@ -140,8 +140,9 @@ int gsr_exclusive_scan_u8(const uint8_t* in, uint32_t* out, int64_t n, void* ws,
 //                      supergroups before its own (<= 64 rows), the groups before its own inside its supergroup (<= 31
 //                      rows), plus its tile_pre row.  All rows are block-major (one coalesced row of NB counters per load)
 //                      and L2-resident; the loads are issued behind the tile's own key loads.
-// G = smallest power of two with nblocks / G <= 512 (at most 32: the group's histograms live in LDS side by side), so up
-// to 33 M pairs there are at most 16 supergroups and a scatter workgroup fetches all its rows in one round trip.
+// G = smallest power of two with nblocks / G <= 512 up to ~4 M pairs (at most 16 supergroups: a scatter workgroup fetches
+// all its rows in one round trip), <= 2048 beyond (at most 32 tiles per group: the group's histograms live in LDS side by
+// side).
 #define RS_BLOCK 256
 #define RS_WAVES (RS_BLOCK / 64)
 // 2048 pairs per workgroup: the depth sort of 1M Gaussians then has 489 workgroups (two per CU) instead of 245 (fewer
@@ -164,8 +165,13 @@ struct RsGeom {
     explicit RsGeom(int64_t n) {
         nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
         if (nblocks < 1) nblocks = 1;
+        // up to ~4 M pairs the sort is latency-bound and a scatter workgroup should fetch its rows in one round trip
+        // (<= 512 groups = 16 supergroups); beyond that it is throughput-bound, the histogram kernel needs its parallelism
+        // back (345 workgroups walking 32 tiles each took 60 us per launch at 22.6 M pairs inside the step) and a few more
+        // row batches per scatter workgroup disappear behind the other resident workgroups: <= 2048 groups
+        const int target = nblocks <= 2048 ? RS_GROUPS_TARGET : 4 * RS_GROUPS_TARGET;
         G = 1;
-        while ((nblocks + G - 1) / G > RS_GROUPS_TARGET && G < RS_MAX_G) G <<= 1;
+        while ((nblocks + G - 1) / G > target && G < RS_MAX_G) G <<= 1;
         ngroups = (nblocks + G - 1) / G;
         nsuper = (ngroups + RS_SUPER - 1) / RS_SUPER;
     }
@@ -609,7 +615,9 @@ __global__ void __launch_bounds__(256) finalize_bins_kernel(int D, const uint32_
                                                             uint32_t* __restrict__ ranges, uint8_t* __restrict__ slot_cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D) return;
-    if (slot_cnt) slot_cnt[i] = 0;
+    // 16 bytes per store from every 16th thread (the region is padded to 256 bytes): one byte per thread cost 0.14 ms at
+    // D = 22.6 M, a byte-masked store being charged its whole sector
+    if (slot_cnt && (i & 15) == 0) *reinterpret_cast<uint4*>(slot_cnt + i) = make_uint4(0u, 0u, 0u, 0u);
     const uint32_t t = tile_sorted[i];
     const uint32_t tp = i > 0 ? tile_sorted[i - 1] : 0xFFFFFFFFu;
     if (i == 0) ranges[2 * t] = 0;

@@ -684,7 +684,12 @@ def rasterize_debug(means3D, opacities, shs=None, colors_precomp=None, scales=No
     for which, fields in spec.items():
         buf = alloc.buffers[which]
         for name, dt, shape in fields:
-            off, nbytes = _lib.buffer_field(which, name, N, D, W, H)
+            try:
+                off, nbytes = _lib.buffer_field(which, name, N, D, W, H)
+            except _lib.GsrError:
+                if name != "covered":      # (an older build of the library, loaded through GSR_LIB_PATH for an A/B run)
+                    raise
+                continue
             res[name] = buf[off:off + nbytes].view(dt).reshape(shape) if nbytes else \
                 torch.empty(0, dtype=dt, device=device).reshape([s if s >= 0 else 0 for s in shape])
     # first emission index of every Gaussian (depth rank r = order^-1): offs is indexed by rank
