@@ -32,24 +32,19 @@
 #ifndef RB_MIN_WAVES
 #define RB_MIN_WAVES 6   // <= 80 VGPRs; the kernel needs 72 without scratch, so seven waves per SIMD run (LDS: 7 x 20 KB)
 #endif
-// FEAT16: see render_fwd.hip -- 0 = RGB from the record, 1..4 = up to 16*FEAT16 feature channels by id.
+// (Wide per-pixel payloads have their own kernel: render_bwd_wide.hip.)
 // PROBE (developer builds only: make PROBES=1, scripts/dev_probe.py): 1 = eight more dependent VALU per iteration,
 // 4 = eight more dependent SALU, 3 = no row store (WRONG gradients: it exists to time the loop), 6 = 20 KB more LDS per
 // workgroup (fewer waves per SIMD), 8 = four LDS reads of the record instead of five (WRONG gradients).
-template <int FEAT16, int PROBE = 0>
-__global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) render_bwd_kernel(RenderBwdParams p) {
+template <int PROBE = 0>
+__global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(RenderBwdParams p) {
     __shared__ float s_probe_pad[PROBE == 6 ? 5120 : 1];
     if (PROBE == 6 && p.W < 0) s_probe_pad[threadIdx.x] = 1.f;
     __shared__ float4 s_rec_all[RB_WAVES][64 * 5];
-    // wide payload, up to 32 channels: features of the staged entries this quad touched, [entry][channel] (see render_fwd)
-    constexpr bool STAGE_FEAT = FEAT16 == 1 || FEAT16 == 2;
-    constexpr int NQ = STAGE_FEAT ? 4 * FEAT16 : 1;
-    __shared__ float4 s_feat_all[STAGE_FEAT ? RB_WAVES : 1][STAGE_FEAT ? 64 * 4 * FEAT16 : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     float4* s_rec = s_rec_all[wave];
-    float4* s_feat = s_feat_all[STAGE_FEAT ? wave : 0];
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b
     // takes tile (b % 8) * per_xcd + b / 8 -- every XCD owns one contiguous band of tiles, and the records shared by
     // neighbouring tiles are fetched into ONE L2 instead of several
@@ -90,20 +85,10 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
     const int median_contributor = inside ? (int)p.n_contrib[pix_id + HW] : 0;
 
     float dL_dpix0 = 0.f, dL_dpix1 = 0.f, dL_dpix2 = 0.f;
-    constexpr int NF = FEAT16 > 0 ? 16 * FEAT16 : 1;
-    float dL_dpixf[NF];
-#pragma unroll
-    for (int k = 0; k < NF; ++k) dL_dpixf[k] = 0.f;
     float dL_ddepth = 0.f, dL_daccum = 0.f, dL_dreg = 0.f, dL_dmedian = 0.f;
     float dL_dn0 = 0.f, dL_dn1 = 0.f, dL_dn2 = 0.f;
     if (inside) {
-        if (FEAT16 == 0) {
-            dL_dpix0 = p.dL_dcolor[pix_id]; dL_dpix1 = p.dL_dcolor[pix_id + HW]; dL_dpix2 = p.dL_dcolor[pix_id + 2 * HW];
-        } else {
-#pragma unroll
-            for (int k = 0; k < NF; ++k)
-                if (k < p.C) dL_dpixf[k] = p.dL_dcolor[pix_id + (size_t)k * HW];
-        }
+        dL_dpix0 = p.dL_dcolor[pix_id]; dL_dpix1 = p.dL_dcolor[pix_id + HW]; dL_dpix2 = p.dL_dcolor[pix_id + 2 * HW];
         dL_ddepth = p.dL_dallmap[pix_id + 0 * HW];
         dL_daccum = p.dL_dallmap[pix_id + 1 * HW];
         dL_dn0 = p.dL_dallmap[pix_id + 2 * HW];
@@ -112,14 +97,7 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
         dL_dmedian = p.dL_dallmap[pix_id + 5 * HW];
         dL_dreg = p.dL_dallmap[pix_id + 6 * HW];
     }
-    float bg_dot_dpixel = 0.f;
-    if (FEAT16 == 0) {
-        bg_dot_dpixel = p.bg[0] * dL_dpix0 + p.bg[1] * dL_dpix1 + p.bg[2] * dL_dpix2;
-    } else {
-#pragma unroll
-        for (int k = 0; k < NF; ++k)
-            if (k < p.C) bg_dot_dpixel += p.bg[k] * dL_dpixf[k];
-    }
+    const float bg_dot_dpixel = p.bg[0] * dL_dpix0 + p.bg[1] * dL_dpix1 + p.bg[2] * dL_dpix2;
 
     const bool quad_has_dist = __any(dL_dreg != 0.f), quad_has_median = __any(dL_dmedian != 0.f);   // wave-uniform
     const bool quad_has_surf = __any(dL_ddepth != 0.f || dL_daccum != 0.f || dL_dn0 != 0.f || dL_dn1 != 0.f || dL_dn2 != 0.f);
@@ -161,17 +139,6 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
         // through two ds_bpermute per iteration)
         s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_rec[lane * 5 + 3] = pf3;
         s_rec[lane * 5 + 4] = make_float4(pf4.x, pf4.y, __uint_as_float(slot_of_lane), __uint_as_float(touch_of_lane));
-        const uint32_t id_of_lane = ids_cur;          // Gaussian id of staged entry `lane` (wide payload only)
-        float4 ft[NQ];
-        const bool feat_needed = STAGE_FEAT && lane < nb && ((touch_of_lane >> (8 * wave)) & 0xFu) != 0u;
-        if (STAGE_FEAT) {   // issued before the next batch's prefetch, so waiting for them does not wait for it
-            const float4* fsrc = reinterpret_cast<const float4*>(p.feat + (size_t)id_of_lane * p.C);
-#pragma unroll
-            for (int k = 0; k < NQ; ++k) {
-                ft[k] = zero4;
-                if (feat_needed && 4 * k < p.C) ft[k] = fsrc[k];
-            }
-        }
         {   // prefetch the next (shallower) batch
             const int hi2 = lo, lo2 = max(0, hi2 - 64), cnt = hi2 - lo2;
             pf_slot = lane < cnt ? p.slot_off[rows_nxt] : 0u;
@@ -180,14 +147,6 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
             const int lo3 = max(0, lo2 - 64), cnt3 = lo2 - lo3;
             ids_nxt = lane < cnt3 ? p.point_list[r0 + lo3 + lane] : 0u;
             rows_nxt = lane < cnt3 ? p.inst_row[r0 + lo3 + lane] : 0u;
-        }
-        if (STAGE_FEAT) {
-            // EVERY slot is written (zeros where the features were not fetched): a block whose mask is empty this
-            // iteration evaluates a dummy entry with weight 0, and 0 x (stale LDS bits that happen to be NaN) would poison
-            // its suffix recursion
-#pragma unroll
-            for (int k = 0; k < NQ; ++k)
-                if (4 * k < p.C) s_feat[lane * NQ + k] = feat_needed ? ft[k] : zero4;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -231,11 +190,8 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
             GsrPair pr;
             const bool ok = gsr_pair_eval(pxf, pyf, a0, a1, a2, a3.z, pr);
             const bool active = has && cidx < last_contributor && ok;
-            // Gaussian id of this row's entry (wide payload)
-            const uint32_t gid = FEAT16 > 0 ? (uint32_t)__shfl((int)id_of_lane, j, 64) : 0u;
             float gT[9];
             float gxy0, gxy1, gn0, gn1, gn2, gopa, gc0, gc1, gc2;
-            float w_pair;   // blending weight of this pair (wide payload: d feature = w * dL/dpixel)
             uint32_t rec_slot, rec_touch;   // first gradient row and touch word of this row's entry (staged with the record)
             {
                 const float4 a4 = s_rec[j * 5 + 4];
@@ -246,7 +202,6 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
                 const float inv_oma = gsr_rcp(one_m_alpha);
                 T = T * inv_oma;
                 const float w = alpha * T;
-                w_pair = w;
 
                 // colour, expected depth, alpha and normal share one suffix recursion:
                 //   q_i = c_i . dL/dC + z_i dL/dD + 1 dL/dA + n_i . dL/dN
@@ -255,21 +210,7 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
                 // (the surface channels -- depth, alpha, normal -- carry no gradient before the regularizers switch on)
                 float q = 0.f;
                 if (quad_has_surf) q = c_d * dL_ddepth + dL_daccum + n0 * dL_dn0 + n1 * dL_dn1 + n2 * dL_dn2;
-                if (FEAT16 == 0) {
-                    q += c0 * dL_dpix0 + c1 * dL_dpix1 + c2 * dL_dpix2;
-                } else {
-                    const float4* f = STAGE_FEAT ? s_feat + j * NQ      // per-row LDS address
-                                                 : reinterpret_cast<const float4*>(p.feat + (size_t)gid * p.C);
-                    float qc = 0.f;
-#pragma unroll
-                    for (int k = 0; k < NF / 4; ++k) {
-                        if (4 * k < p.C) {
-                            const float4 v = f[k];
-                            qc += v.x * dL_dpixf[4 * k] + v.y * dL_dpixf[4 * k + 1] + v.z * dL_dpixf[4 * k + 2] + v.w * dL_dpixf[4 * k + 3];
-                        }
-                    }
-                    q += qc;
-                }
+                q += c0 * dL_dpix0 + c1 * dL_dpix1 + c2 * dL_dpix2;
                 acc_q = last_alpha * last_q + (1.f - last_alpha) * acc_q;
                 last_q = q;
                 float dL_dalpha = q - acc_q;
@@ -339,20 +280,6 @@ __global__ void __launch_bounds__(RB_BLOCK, FEAT16 == 0 ? RB_MIN_WAVES : 2) rend
                     float* row = p.grad_rows + slot * RB_ROW;
                     row[l16 < 9 ? l16 : l16 + 2] = tot;                       // skip the two xy columns
                     if ((l16 & 7) == 0) row[GSR_GR_XY + (l16 >> 3)] = xy;
-                }
-                if (FEAT16 > 0) {   // 16 channels per butterfly; lane c of the row ends up holding channel c of the group
-                    float* frow = p.feat_rows + slot * p.C;
-#pragma unroll
-                    for (int fg = 0; fg < FEAT16; ++fg) {
-                        if (16 * fg < p.C) {
-                            float f16[16];
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) f16[k] = w_pair * dL_dpixf[16 * fg + k];
-                            const float ft = row_sum16_transposed(f16, l16);
-                            const int ch = 16 * fg + l16;
-                            if (has && ch < p.C) frow[ch] = ft;
-                        }
-                    }
                 }
             }
         }
@@ -488,31 +415,19 @@ int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32
 #ifdef GSR_DEV_PROBES
         const char* e = getenv("GSR_K7_PROBE");   // re-read per launch
         switch (e ? atoi(e) : 0) {
-            case 1: hipLaunchKernelGGL((render_bwd_kernel<0, 1>), grid, block, 0, s, p); break;
-            case 3: hipLaunchKernelGGL((render_bwd_kernel<0, 3>), grid, block, 0, s, p); break;
-            case 4: hipLaunchKernelGGL((render_bwd_kernel<0, 4>), grid, block, 0, s, p); break;
-            case 6: hipLaunchKernelGGL((render_bwd_kernel<0, 6>), grid, block, 0, s, p); break;
-            case 8: hipLaunchKernelGGL((render_bwd_kernel<0, 8>), grid, block, 0, s, p); break;
-            default: hipLaunchKernelGGL((render_bwd_kernel<0>), grid, block, 0, s, p);
+            case 1: hipLaunchKernelGGL((render_bwd_kernel<1>), grid, block, 0, s, p); break;
+            case 3: hipLaunchKernelGGL((render_bwd_kernel<3>), grid, block, 0, s, p); break;
+            case 4: hipLaunchKernelGGL((render_bwd_kernel<4>), grid, block, 0, s, p); break;
+            case 6: hipLaunchKernelGGL((render_bwd_kernel<6>), grid, block, 0, s, p); break;
+            case 8: hipLaunchKernelGGL((render_bwd_kernel<8>), grid, block, 0, s, p); break;
+            default: hipLaunchKernelGGL((render_bwd_kernel<>), grid, block, 0, s, p);
         }
 #else
-        hipLaunchKernelGGL((render_bwd_kernel<0>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((render_bwd_kernel<>), grid, block, 0, s, p);
 #endif
     } else {
-        // GSR_WIDE_BWD=scalar (read per launch): the round-2 form (C fmas + one butterfly per 16 channels and iteration), kept for A/B
-        const char* e = getenv("GSR_WIDE_BWD");
-        if (e && e[0] == 's') {
-            switch ((v.channels + 15) / 16) {
-                case 1: hipLaunchKernelGGL(render_bwd_kernel<1>, grid, block, 0, s, p); break;
-                case 2: hipLaunchKernelGGL(render_bwd_kernel<2>, grid, block, 0, s, p); break;
-                case 3: hipLaunchKernelGGL(render_bwd_kernel<3>, grid, block, 0, s, p); break;
-                case 4: hipLaunchKernelGGL(render_bwd_kernel<4>, grid, block, 0, s, p); break;
-                default: gsr_set_error("wide payload supports at most 64 channels"); return GSR_E_UNSUPPORTED;
-            }
-        } else {
-            const int rc = gsr_launch_render_bwd_wide(p, v.channels, grid, s);
-            if (rc != GSR_OK) return rc;
-        }
+        const int rc = gsr_launch_render_bwd_wide(p, v.channels, grid, s);   // render_bwd_wide.hip
+        if (rc != GSR_OK) return rc;
     }
     GSR_LAUNCH_CHECK();
     return GSR_OK;

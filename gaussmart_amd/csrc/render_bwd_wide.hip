@@ -2,7 +2,7 @@
 // render_fwd's FEAT16 > 0 kernels.  Same replay as render_bwd.hip -- wave = 8x8 quad, DPP row = 4x4 pixel block walking its
 // own list back to front, geometry gradients summed over the block with the transposed butterfly into dense rows -- but the
 // two C-wide pieces run on the MATRIX pipe instead of the vector unit (round 2 ran them as C fmas + one 16-lane butterfly
-// per 16 channels and iteration: 4.2 ms at C = 64 against 0.65 ms for RGB):
+// per 16 channels and iteration: 1.38 ms at C = 16, 4.2 ms at C = 64 against 0.65 ms for RGB; this: 0.99 / 2.3 ms):
 //   q[pixel][entry]   = sum_ch f[entry][ch] * dL/dpixel[pixel][ch]          (the colour term of the suffix recursion)
 //   frow[entry][ch]   = sum_{pixels of the block} w[pixel][entry] * dL/dpixel[pixel][ch]    (the feature gradient rows)
 // Both are products with the per-pixel gradient, which is constant for the wave's whole life.  A block's pending entries are
@@ -10,8 +10,8 @@
 //   1. Q: v_mfma_f32_16x16x1_4b_f32 (4 blocks = the 4 DPP rows, K = 1) once per channel: A = feature ch of "my window entry"
 //      (lane (b, t) owns entry t of block b's window and loads its feature row itself), B = dL/dpixel[ch] of "my pixel" (lane
 //      (b, px) -- the natural lane = pixel layout), D[t][px] goes to a 4 KiB LDS tile from which iteration t reads its q;
-//   2. the 16 iterations: the RGB kernel's body with q taken from the tile; every lane parks its blending weight w in a
-//      second LDS tile [block][t][pixel];
+//   2. the 16 iterations: the RGB kernel's body with q taken from the tile; every lane parks its blending weight w in the
+//      word it has just read q from (tile [block][t][pixel]);
 //   3. rows: once per pixel index p and 16-channel tile: A = w[t][p] (lane (b, t) reads its row of the weight tile), B =
 //      dL/dpixel of pixel p with the CHANNELS on the lanes (a second, transposed register copy of the gradient made once per
 //      wave through LDS), D[t][ch] leaves straight for the feature rows.
@@ -26,12 +26,13 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int NM>   // 16-channel tiles: C <= 16 NM
-__global__ void __launch_bounds__(RB_BLOCK, NM == 1 ? 3 : 2) render_bwd_wide_kernel(RenderBwdParams p) {
+__global__ void __launch_bounds__(RB_BLOCK, NM == 1 ? 4 : (NM == 2 ? 3 : 2)) render_bwd_wide_kernel(RenderBwdParams p) {
     __shared__ float4 s_rec_all[RB_WAVES][64 * 5];
     __shared__ int s_win_all[RB_WAVES][4][16];          // [block][t] -> staged entry of the batch, -1: none
     __shared__ uint32_t s_slot_all[RB_WAVES][4][16];    // [block][t] -> gradient row of (entry, block), 0xFFFFFFFF: none
-    __shared__ float s_q_all[RB_WAVES][4][16][16];      // [block][t][pixel of the block]: colour term of q
-    __shared__ float s_w_all[RB_WAVES][4][16][16];      // [block][t][pixel of the block]: blending weight
+    // [block][t][pixel of the block]: the colour term of q until iteration t has read it, that pixel's blending weight
+    // afterwards (same lane, same word: one 4 KiB tile per wave instead of two keeps four workgroups on a CU)
+    __shared__ float s_q_all[RB_WAVES][4][16][16];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -39,7 +40,6 @@ __global__ void __launch_bounds__(RB_BLOCK, NM == 1 ? 3 : 2) render_bwd_wide_ker
     int (*s_win)[16] = s_win_all[wave];
     uint32_t (*s_slot)[16] = s_slot_all[wave];
     float (*s_q)[16][16] = s_q_all[wave];
-    float (*s_w)[16][16] = s_w_all[wave];
     const int tile_lin = (int)(blockIdx.x & 7u) * p.per_xcd + (int)(blockIdx.x >> 3);   // XCD-aware tile order (render_bwd.hip)
     if (tile_lin >= p.n_tiles) return;
     const int tile_y = tile_lin / p.gx, tile_x = tile_lin - tile_y * p.gx;
@@ -232,10 +232,9 @@ __global__ void __launch_bounds__(RB_BLOCK, NM == 1 ? 3 : 2) render_bwd_wide_ker
                     const float inv_oma = gsr_rcp(one_m_alpha);
                     T = T * inv_oma;
                     const float w = alpha * T;
-                    s_w[grp][t][l16] = w;                       // the A operand of the row products
-
                     const float n0 = a2.w, n1 = a3.x, n2 = a3.y;
                     float q = s_q[grp][t][l16];                 // colour term: sum_ch f[ch] dL/dpixel[ch]
+                    s_q[grp][t][l16] = w;                       // ... replaced by the A operand of the row products
                     if (quad_has_surf) q += c_d * dL_ddepth + dL_daccum + n0 * dL_dn0 + n1 * dL_dn1 + n2 * dL_dn2;
                     acc_q = last_alpha * last_q + (1.f - last_alpha) * acc_q;
                     last_q = q;
@@ -310,7 +309,7 @@ __global__ void __launch_bounds__(RB_BLOCK, NM == 1 ? 3 : 2) render_bwd_wide_ker
                 const bool ran = s_slot[grp][l16] != 0xFFFFFFFFu;
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) {
-                    const float4 v = *reinterpret_cast<const float4*>(&s_w[grp][l16][4 * c4]);
+                    const float4 v = *reinterpret_cast<const float4*>(&s_q[grp][l16][4 * c4]);
                     wa[4 * c4] = ran ? v.x : 0.f; wa[4 * c4 + 1] = ran ? v.y : 0.f; wa[4 * c4 + 2] = ran ? v.z : 0.f; wa[4 * c4 + 3] = ran ? v.w : 0.f;
                 }
                 uint32_t sl[4][4];  // rows of (block b, t = 4 grp + r)
