@@ -176,6 +176,13 @@ static hipEvent_t* color_events() {
     return ev;
 }
 
+// up to this many workgroups of the geometry pass the host adds their count partials itself (8 M Gaussians);
+// GSR_COUNT_FUSED_MAX_BLOCKS (read per call) lets a test take the other branch at a small size
+static int fused_count_max_blocks() {
+    const char* e = getenv("GSR_COUNT_FUSED_MAX_BLOCKS");
+    return e && *e ? atoi(e) : 32768;
+}
+
 static inline int bits_for(uint32_t n_values) {   // bits needed to represent 0..n_values-1
     int b = 0;
     while ((1ull << b) < n_values) ++b;
@@ -255,7 +262,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         // same launch clears the depth sort's supergroup table.  Above 8 M Gaussians a small counting kernel produces
         // <= 256 partials instead (the host would add up tens of thousands).
         const int pre_blocks = gsr_preprocess_fwd_blocks(N);
-        const bool fused_count = pre_blocks <= 32768;
+        const bool fused_count = pre_blocks <= fused_count_max_blocks();
         int n_partial = fused_count ? pre_blocks : GSR_COUNT_PARTIALS;
         unsigned long long* d_host = pinned_words((size_t)n_partial);
         if (!d_host) { gsr_set_error("hipHostMalloc failed (instance-count read-back buffer)"); return GSR_E_HIP; }

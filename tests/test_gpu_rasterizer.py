@@ -141,6 +141,19 @@ def test_render_forward_parity(gpu_device, n, w, h, seed, bg):
     assert int(((med_h != out.n_contrib[1]) & stable & (m["m_med"] > 1e-4)).sum()) == 0
 
 
+def test_instance_count_by_the_separate_kernel_is_the_same(gpu_device, monkeypatch):
+    """Above 8 M Gaussians the instance count comes from a small counting kernel instead of the geometry pass's own
+    partial sums (gsr_api.hip); GSR_COUNT_FUSED_MAX_BLOCKS forces that branch at a size a test can afford."""
+    p, cam = make_scene(5000, 250, 130, seed=3)
+    a = activate(p)
+    ref = _debug(a, cam, gpu_device)
+    monkeypatch.setenv("GSR_COUNT_FUSED_MAX_BLOCKS", "1")
+    alt = _debug(a, cam, gpu_device)
+    assert alt["num_rendered"] == ref["num_rendered"] > 0
+    for k in ("color", "allmap", "radii", "point_list", "ranges", "inst_row"):
+        assert torch.equal(alt[k], ref[k]), k
+
+
 def _grad_compare(a, cam, dev, flags, bg=(0.2, 0.4, 0.6), colors=None, cov=None, seed=1, deg=3, scale_modifier=1.0):
     from gaussmart_amd.rasterizer import GaussianRasterizer
     N = a["means3D"].shape[0]

@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("n,lo,hi", [(1, 0, 32), (63, 0, 32), (4096, 0, 32), (4097, 0, 13), (100_003, 0, 32),
-                                      (1_000_000, 0, 13), (3_000_001, 3, 17), (250_000, 0, 1), (70_000, 5, 5)])
+                                      (1_000_000, 0, 13), (3_000_001, 3, 17), (250_000, 0, 1), (70_000, 5, 5),
+                                      (6_000_000, 0, 12)])     # > 2048 tiles: the histogram groups' other size policy
 def test_radix_sort_bit_exact_and_stable(gpu_device, n, lo, hi):
     from gaussmart_amd.knn import sort_pairs_u32
     rng = np.random.default_rng(n)
