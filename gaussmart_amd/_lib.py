@@ -137,6 +137,11 @@ def lib():
         L.gsr_adam_step.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_float),
                                     C.POINTER(C.c_float), C.c_double, C.c_double, C.c_double, C.c_void_p]
+        L.gsr_adam_step_keep.restype = C.c_int32
+        L.gsr_adam_step_keep.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_float),
+                                         C.POINTER(C.c_float), C.c_double, C.c_double, C.c_double, C.POINTER(C.c_void_p),
+                                         C.c_void_p]
         L.gsr_adam_sh_factored.restype = C.c_int32
         L.gsr_adam_sh_factored.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                            C.c_int64, C.c_void_p, C.c_int32, C.c_float,

@@ -28,6 +28,7 @@ struct AdamBatch {
     long long n[AD_MAX_TENSORS];
     float step_size[AD_MAX_TENSORS];     // lr / (1 - beta1^t)
     float inv_bc2_sqrt[AD_MAX_TENSORS];  // 1 / sqrt(1 - beta2^t)
+    float* old[AD_MAX_TENSORS];          // NULL, or where the parameter's value BEFORE the update is kept (gsr_adam_step_keep)
 };
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float omb1, float b2, float omb2,
@@ -43,6 +44,7 @@ __global__ void __launch_bounds__(AD_BLOCK) adam_kernel(AdamBatch b) {
     if (t >= b.count) return;
     float* __restrict__ p = b.p[t]; const float* __restrict__ g = b.g[t];
     float* __restrict__ m = b.m[t]; float* __restrict__ v = b.v[t];
+    float* __restrict__ old = b.old[t];
     const long long n = b.n[t];
     const float ss = b.step_size[t], ib = b.inv_bc2_sqrt[t];
     const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
@@ -53,6 +55,7 @@ __global__ void __launch_bounds__(AD_BLOCK) adam_kernel(AdamBatch b) {
         // gradients and moments are touched once per step: non-temporal, so that they do not evict the parameters
         // (which the next forward reads) from the 256 MB Infinity Cache
         float4 pp = reinterpret_cast<float4*>(p)[i];
+        if (old) reinterpret_cast<float4*>(old)[i] = pp;
         const float4 gg = nt_load4(g, i);
         float4 mm = nt_load4(m, i), vv = nt_load4(v, i);
         adam_one(pp.x, gg.x, mm.x, vv.x, b.omb1, b.beta2, b.omb2, b.eps, ss, ib);
@@ -65,6 +68,7 @@ __global__ void __launch_bounds__(AD_BLOCK) adam_kernel(AdamBatch b) {
     }
     for (long long i = n4 * 4 + (long long)blockIdx.x * AD_BLOCK + threadIdx.x; i < n; i += stride) {
         float pp = p[i], mm = m[i], vv = v[i];
+        if (old) old[i] = pp;
         adam_one(pp, g[i], mm, vv, b.omb1, b.beta2, b.omb2, b.eps, ss, ib);
         p[i] = pp; m[i] = mm; v[i] = vv;
     }
@@ -74,6 +78,14 @@ extern "C" int32_t gsr_adam_step(int32_t count, float* const* params, const floa
                                  float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
                                  const float* step_size, const float* inv_bc2_sqrt, double beta1, double beta2,
                                  double eps, gsr_stream_t stream_) {
+    return gsr_adam_step_keep(count, params, grads, exp_avg, exp_avg_sq, numel, step_size, inv_bc2_sqrt, beta1, beta2, eps,
+                              nullptr, stream_);
+}
+
+extern "C" int32_t gsr_adam_step_keep(int32_t count, float* const* params, const float* const* grads,
+                                      float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                                      const float* step_size, const float* inv_bc2_sqrt, double beta1, double beta2,
+                                      double eps, float* const* keep_old, gsr_stream_t stream_) {
     if (count < 0 || count > AD_MAX_TENSORS) { gsr_set_error("adam: at most %d tensors per call", AD_MAX_TENSORS); return GSR_E_INVALID; }
     if (count == 0) return GSR_OK;
     if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !step_size || !inv_bc2_sqrt) { gsr_set_error("adam: null argument"); return GSR_E_INVALID; }
@@ -88,6 +100,7 @@ extern "C" int32_t gsr_adam_step(int32_t count, float* const* params, const floa
         }
         b.p[i] = params[i]; b.g[i] = grads[i]; b.m[i] = exp_avg[i]; b.v[i] = exp_avg_sq[i]; b.n[i] = numel[i];
         b.step_size[i] = step_size[i]; b.inv_bc2_sqrt[i] = inv_bc2_sqrt[i];
+        b.old[i] = keep_old ? keep_old[i] : nullptr;
         if (numel[i] > max_n) max_n = numel[i];
     }
     if (max_n == 0) return GSR_OK;

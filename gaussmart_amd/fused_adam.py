@@ -74,10 +74,12 @@ class FusedAdam(torch.optim.Adam):
         return cc[1]
 
     @torch.no_grad()
-    def step(self, closure=None, only=None, stream=None):
+    def step(self, closure=None, only=None, stream=None, keep_old=None):
         """`only`: iterable of parameters to update (the others keep their state and step count untouched);
         `stream`: torch.cuda.Stream to launch on instead of the current one.  Both serve the pipelined
-        data-parallel step, which updates the geometry tensors and the SH tensors at different times."""
+        data-parallel step, which updates the geometry tensors and the SH tensors at different times.
+        `keep_old`: (parameter, tensor of its shape) -- the update kernel also stores the parameter's values BEFORE the
+        update there (gsr_adam_step_keep), which replaces a copy launch beside the step."""
         only_ids = None if only is None else {id(p) for p in only}
         self._writes += 1
         loss = None
@@ -93,11 +95,14 @@ class FusedAdam(torch.optim.Adam):
                 records = rec.gathered if rec.gathered is not None else rec.record
                 if self.next_view is not None and rec.xyz.grad is not None:
                     # the SH step will also evaluate the NEXT view's colour, which needs the positions AFTER their own
-                    # update: snapshot the positions the backward saw, update the geometry below, then the SH tensors
-                    sh_after = (f_dc, f_rest, rec, records, self._snapshot_xyz(rec.xyz, stream))
+                    # update: the geometry step below keeps the positions the backward saw (keep_old), then the SH tensors
+                    if keep_old is None:
+                        keep_old = (rec.xyz, self._snapshot_buffer(rec.xyz))
+                    sh_after = (f_dc, f_rest, rec, records, keep_old[1])
                 else:       # first: it reads the positions the backward saw, which the launch below updates
                     self.step_sh_factored(f_dc, f_rest, rec.xyz, records, rec.n_views, rec.record.numel(), rec.sh_degree,
                                           rec.grad_scale, stream=stream)
+        kept = False
         batches = {}
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
@@ -124,10 +129,20 @@ class FusedAdam(torch.optim.Adam):
                     chunk = items[i:i + self.MAX_TENSORS]
                     n = len(chunk)
                     arr = lambda k: (C.c_void_p * n)(*[c[k].data_ptr() for c in chunk])
-                    _lib.check(L.gsr_adam_step(
+                    olds = None
+                    if keep_old is not None and any(c[0] is keep_old[0] for c in chunk):
+                        kept = True
+                        olds = (C.c_void_p * n)(*[keep_old[1].data_ptr() if c[0] is keep_old[0] else None for c in chunk])
+                    _lib.check(L.gsr_adam_step_keep(
                         n, arr(0), arr(1), arr(2), arr(3), (C.c_int64 * n)(*[c[0].numel() for c in chunk]),
                         (C.c_float * n)(*[c[4] for c in chunk]), (C.c_float * n)(*[c[5] for c in chunk]),
-                        beta1, beta2, eps, C.c_void_p(stream_h)))
+                        beta1, beta2, eps, olds, C.c_void_p(stream_h)))
+        if keep_old is not None and not kept:      # the parameter took no update this step: its old value is its value
+            if stream is not None:
+                with torch.cuda.stream(stream):
+                    keep_old[1].copy_(keep_old[0])
+            else:
+                keep_old[1].copy_(keep_old[0])
         if sh_after is not None:
             f_dc, f_rest, rec, records, xyz_old = sh_after
             self.step_sh_factored(f_dc, f_rest, xyz_old, records, rec.n_views, rec.record.numel(), rec.sh_degree,
@@ -142,22 +157,17 @@ class FusedAdam(torch.optim.Adam):
         order is snapshot -> geometry -> SH + colour of the next view from the NEW positions."""
         stride, deg = rec.record.numel(), rec.sh_degree
         if self.next_view is not None and rec.xyz.grad is not None:
-            xyz_old = self._snapshot_xyz(rec.xyz)
-            self.step()
+            xyz_old = self._snapshot_buffer(rec.xyz)
+            self.step(keep_old=(rec.xyz, xyz_old))
             self.step_sh_factored(f_dc, f_rest, xyz_old, records, n_views, stride, deg, grad_scale,
                                   next_view=self.next_view, xyz_next=rec.xyz)
         else:
             self.step_sh_factored(f_dc, f_rest, rec.xyz, records, n_views, stride, deg, grad_scale)
             self.step()
 
-    def _snapshot_xyz(self, xyz, stream=None):
+    def _snapshot_buffer(self, xyz):
         if self._xyz_old is None or self._xyz_old.shape != xyz.shape or self._xyz_old.device != xyz.device:
             self._xyz_old = torch.empty_like(xyz)
-        if stream is not None:
-            with torch.cuda.stream(stream):
-                self._xyz_old.copy_(xyz)
-        else:
-            self._xyz_old.copy_(xyz)
         return self._xyz_old
 
     @torch.no_grad()

@@ -259,23 +259,18 @@ class ViewParallel:
             records, w_rec = self._gather_records(rec, True)
         if self._xyz_snap is None or self._xyz_snap.shape != rec.xyz.shape or self._xyz_snap.device != dev:
             self._xyz_snap = torch.empty_like(rec.xyz)
-        self._xyz_snap.copy_(rec.xyz)
-        snapped = torch.cuda.Event()
-        snapped.record(torch.cuda.current_stream(dev))
         if w_head is not None:
             self._wait_on_main(w_head, dev)               # current stream waits for the geometry collective only
         if self._side is None:
             self._side = torch.cuda.Stream(device=dev)
         next_view = getattr(optimizer, "next_view", None)
-        optimizer.step()                                  # geometry tensors (the features have no .grad: skipped)
-        geo_done = None
-        if next_view is not None:                         # the SH step also evaluates the next view's colour from the NEW
-            geo_done = torch.cuda.Event()                 # positions: it has to run behind the geometry step
-            geo_done.record(torch.cuda.current_stream(dev))
+        # geometry tensors (the features have no .grad: skipped); the same launch leaves the positions the backward saw in
+        # the snapshot (FusedAdam.step(keep_old=...): no copy launch beside it)
+        optimizer.step(keep_old=(rec.xyz, self._xyz_snap))
+        geo_done = torch.cuda.Event()                     # snapshot written; and -- for the next view's colour, evaluated
+        geo_done.record(torch.cuda.current_stream(dev))   # from the NEW positions -- the geometry step done
         with torch.cuda.stream(self._side):
-            self._side.wait_event(snapped)
-            if geo_done is not None:
-                self._side.wait_event(geo_done)
+            self._side.wait_event(geo_done)
             if w_rec is not None:
                 w_rec.wait()
             optimizer.step_sh_factored(f_dc, f_rest, self._xyz_snap, records, n_views, stride, deg, scale, stream=self._side,

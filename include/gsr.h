@@ -251,6 +251,13 @@ int32_t gsr_adam_step(int32_t count, float* const* params, const float* const* g
                       float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
                       const float* step_size, const float* inv_bc2_sqrt, double beta1, double beta2,
                       double eps, gsr_stream_t stream);
+/* The same step; keep_old (may be NULL, entries may be NULL): per tensor a device f32 buffer of numel[i] elements that
+ * receives the parameter's values BEFORE the update, in the same pass (the factored SH step of the next view needs the
+ * positions the backward saw while the positions move: one launch and 24 B per Gaussian less than a copy beside the step). */
+int32_t gsr_adam_step_keep(int32_t count, float* const* params, const float* const* grads,
+                           float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                           const float* step_size, const float* inv_bc2_sqrt, double beta1, double beta2,
+                           double eps, float* const* keep_old, gsr_stream_t stream);
 
 /* Adam step of the two SH parameter tensors (features_dc [N,1,3], features_rest [N,M-1,3]) from FACTORED gradients
  * (GSR_FLAG_FACTORED_SH_GRAD), for the Gaussians [first, first + count):
