@@ -167,8 +167,9 @@ static size_t exact_rows_threshold() {
     return e && *e ? (size_t)strtoull(e, nullptr, 10) : (size_t(8) << 30);
 }
 
-// two timing-less events per calling thread for the colour pass on a second stream (created on first use and kept;
-// re-recording an event does not disturb waits that were enqueued on its previous record)
+// two timing-less events per calling thread -- [0]: end of the geometry pass (the host's wait for the instance count and the
+// colour stream's wait), [1]: end of a colour pass on a second stream -- created on first use and kept; re-recording an
+// event does not disturb waits that were enqueued on its previous record
 static hipEvent_t* color_events() {
     thread_local hipEvent_t ev[2] = {nullptr, nullptr};
     for (int i = 0; i < 2; ++i)
@@ -279,22 +280,20 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
                                            zero_n, zero_n_words, s);
             if (rc != GSR_OK) return rc;
         }
-        struct EventGuard { hipEvent_t e = nullptr; ~EventGuard() { if (e) (void)hipEventDestroy(e); } } evg;
-        GSR_HIP_CHECK(hipEventCreateWithFlags(&evg.e, hipEventDisableTiming));
-        hipEvent_t ev = evg.e;
+        // ONE event behind the geometry pass serves both its readers -- the host (instance count) and, with
+        // GSR_FLAG_DEFER_COLOR, the stream the colour pass runs on: every record on the call's stream is a barrier packet
+        // worth ~6 us of its timeline (two back-to-back records showed as a 14 us hole behind K1 in the kernel trace)
+        hipEvent_t* evs = color_events();
+        if (!evs) { gsr_set_error("hipEventCreate failed (forward events)"); return GSR_E_HIP; }
+        hipEvent_t ev = evs[0];
+        hipStream_t cs = defer_color ? static_cast<hipStream_t>(alloc(ctx, GSR_BUF_COLOR_STREAM, 0)) : nullptr;
         hipError_t e2 = hipEventRecord(ev, s);
-        if (defer_color) {
-            hipStream_t cs = static_cast<hipStream_t>(alloc(ctx, GSR_BUF_COLOR_STREAM, 0));
-            if (cs && cs != s) {
-                hipEvent_t* ev2 = color_events();
-                if (!ev2) { gsr_set_error("hipEventCreate failed (colour-pass events)"); return GSR_E_HIP; }
-                GSR_HIP_CHECK(hipEventRecord(ev2[0], s));
-                GSR_HIP_CHECK(hipStreamWaitEvent(cs, ev2[0], 0));
-                rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, color_jac, cs);
-                if (rc != GSR_OK) return rc;
-                GSR_HIP_CHECK(hipEventRecord(ev2[1], cs));
-                color_join.done = ev2[1]; color_join.armed = true;
-            }
+        if (e2 == hipSuccess && cs && cs != s) {
+            GSR_HIP_CHECK(hipStreamWaitEvent(cs, ev, 0));
+            rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, color_jac, cs);
+            if (rc != GSR_OK) return rc;
+            GSR_HIP_CHECK(hipEventRecord(evs[1], cs));
+            color_join.done = evs[1]; color_join.armed = true;
         }
         if (e2 == hipSuccess && !defer_color)
             rc = gsr_launch_preprocess_color(*view, *g, splat, clamped, out->radii, color_jac, s);
