@@ -397,7 +397,7 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     const GsrBinLayout BL(num_rendered, gx * gy);
     const GsrImageLayout IL((int64_t)W * H);
 
-    // Gradient rows: one 80-byte row per (instance, 4x4 pixel block the forward blended it into), DENSE in
+    // Gradient rows: one 72-byte row (64 + 8 in two arrays) per (instance, 4x4 pixel block the forward blended it into), DENSE in
     // (emission index, quad, block) order.  Their number R <= 16 D is only known on the device (scan below).
     //   * normally the row buffer is sized for the bound and only its first R rows are ever touched: no host wait;
     //   * when the bound is huge (> GSR_EXACT_ROWS_BYTES, default 8 GiB: tens of millions of instances) R is read
@@ -408,17 +408,19 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
         return GSR_E_UNSUPPORTED;
     }
     const bool wide = view->channels != 3;
-    const size_t row_bytes_each = size_t(GSR_GROW_FLOATS) * 4 + (wide ? size_t(view->channels) * 4 : 0);
+    const size_t row_bytes_each = size_t(GSR_GROW_MAIN + (wide ? 0 : GSR_GROW_XY)) * 4 + (wide ? size_t(view->channels) * 4 : 0);
     const size_t cnt_bytes = 0;     // (the row-count bytes live in BINNING, cleared by the forward)
     const size_t slot_bytes = gsr_align((n_inst + 1) * 4);
     const size_t scan_bytes = gsr_scan_workspace_bytes((int64_t)n_inst);
     const size_t sums_bytes = gsr_align(size_t(N > 0 ? N : 1) * GSR_GROW_FLOATS * 4);
-    char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, cnt_bytes + slot_bytes + scan_bytes + sums_bytes));
+    const size_t begin_bytes = gsr_align(size_t(N + 1) * 4);        // first gradient row of every depth rank
+    char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, cnt_bytes + slot_bytes + scan_bytes + sums_bytes + begin_bytes));
     if (!scratch) { gsr_set_error("allocator returned NULL (backward scratch)"); return GSR_E_ALLOC; }
     uint8_t* slot_cnt = const_cast<uint8_t*>(at<uint8_t>(binning, BL.slot_cnt));
     uint32_t* slot_off = reinterpret_cast<uint32_t*>(scratch + cnt_bytes);
     void* scan_ws = scratch + cnt_bytes + slot_bytes;
     float* row_sums = reinterpret_cast<float*>(scratch + cnt_bytes + slot_bytes + scan_bytes);
+    uint32_t* row_begin = reinterpret_cast<uint32_t*>(scratch + cnt_bytes + slot_bytes + scan_bytes + sums_bytes);
 
     size_t n_rows = n_inst * GSR_SUBROWS;       // the bound
     const uint32_t* touch = at<uint32_t>(binning, BL.touch);
@@ -437,19 +439,23 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
         }
     } else {
         GSR_HIP_CHECK(hipMemsetAsync(slot_off, 0, 8, s));
+        GSR_HIP_CHECK(hipMemsetAsync(row_begin, 0, size_t(N + 1) * 4, s));   // no instance, no rows
     }
-    const size_t rows_bytes = gsr_align(n_rows * GSR_GROW_FLOATS * 4);
+    const size_t main_bytes = gsr_align(n_rows * GSR_GROW_MAIN * 4);
+    const size_t rows_bytes = main_bytes + (wide ? 0 : gsr_align(n_rows * GSR_GROW_XY * 4));   // (wide: dxy rides in the row)
     const size_t feat_bytes = wide ? gsr_align(n_rows * size_t(view->channels) * 4) : 0;   // feature rows
     char* rows_mem = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH2, rows_bytes + feat_bytes));
     if (!rows_mem) { gsr_set_error("allocator returned NULL (gradient rows)"); return GSR_E_ALLOC; }
     float* grad_rows = reinterpret_cast<float*>(rows_mem);
+    float* grad_xy = wide ? nullptr : reinterpret_cast<float*>(rows_mem + main_bytes);
     float* feat_rows = wide ? reinterpret_cast<float*>(rows_mem + rows_bytes) : nullptr;
 
     if (num_rendered > 0) {
         rc = gsr_launch_render_bwd(*view, at<uint32_t>(binning, BL.ranges), at<uint32_t>(binning, BL.covered),
                                    at<uint32_t>(binning, BL.inst_row),
                                    at<float>(geom, GL.splat), touch, slot_off, at<float>(image, IL.final_T),
-                                   at<uint32_t>(image, IL.n_contrib), dL_dcolor, dL_dallmap, grad_rows,
+                                   at<uint32_t>(image, IL.n_contrib), dL_dcolor, dL_dallmap, grad_rows, grad_xy,
+                                   N, at<uint32_t>(geom, GL.offs), row_begin,
                                    wide ? g->colors_precomp : nullptr, at<uint32_t>(binning, BL.point_list), feat_rows, s);
         if (rc != GSR_OK) return rc;
     }
@@ -460,13 +466,12 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     if (factored) { o.dL_dshs = nullptr; o.dL_dshs_rest = nullptr; }
     if (!g->scales) { o.dL_dscales = nullptr; o.dL_drotations = nullptr; }
     if (!g->transmat_precomp) o.dL_dtransmat = nullptr;
-    rc = gsr_launch_reduce_rows(N, at<uint32_t>(geom, GL.order), at<uint32_t>(geom, GL.offs), slot_off, grad_rows,
-                                row_sums, s);
+    rc = gsr_launch_reduce_rows(N, at<uint32_t>(geom, GL.order), row_begin, grad_rows, grad_xy, row_sums, s);
     if (rc != GSR_OK) return rc;
     if (wide) {   // dL_dcolors [N,C] comes from the feature sub-rows, not from the 3 RGB columns of the row sums
         if (num_rendered > 0) {
-            rc = gsr_launch_reduce_feat_rows(N, view->channels, at<uint32_t>(geom, GL.order), at<uint32_t>(geom, GL.offs),
-                                             slot_off, feat_rows, o.dL_dcolors, s);
+            rc = gsr_launch_reduce_feat_rows(N, view->channels, at<uint32_t>(geom, GL.order), row_begin, feat_rows,
+                                             o.dL_dcolors, s);
             if (rc != GSR_OK) return rc;
         } else if (N > 0) {
             GSR_HIP_CHECK(hipMemsetAsync(o.dL_dcolors, 0, size_t(N) * view->channels * 4, s));

@@ -49,17 +49,20 @@ struct GsrProfileScope {
 #define GSR_SP_RGB 15
 #define GSR_SP_RECT 18   // two 32-bit words: (x0 | x1 << 16), (y0 | y1 << 16), signed 16-bit each
 
-// One gradient row per (Gaussian, tile, 8x8 quad) = 4 sub-rows per instance, written by render_bwd
-// (each wave64 owns one quad and writes its own sub-row: no cross-wave combine, no atomics) and
-// summed by preprocess_bwd; a byte flag per sub-row says whether it was written at all:
-// [dTu.xyz dTv.xyz dTw.xyz | dxy | dn.xyz | dopa | drgb | pad pad]
+// One gradient row per (instance, 4x4 pixel block the forward blended it into), written by render_bwd (the 16 lanes of a
+// DPP row own their block's row: no cross-wave combine, no atomics) and summed per Gaussian by reduce_rows.  A row is
+// 72 bytes in two arrays: 16 floats (ONE aligned 64-byte store of the 16 lanes) [dTu.xyz dTv.xyz dTw.xyz | dn.xyz | dopa |
+// drgb] and, in a second array, the two floats of the low-pass branch's centre gradient dxy.  The per-Gaussian sums
+// are rows of GSR_GROW_FLOATS floats: the 16 columns, dxy, two unused.
 #define GSR_GROW_FLOATS 20
+#define GSR_GROW_MAIN 16      // floats of a row in the main array
+#define GSR_GROW_XY 2         // floats of a row in the xy array
 #define GSR_SUBROWS 16        // gradient sub-rows per instance: one per 4x4 pixel block of the 16x16 tile
 #define GSR_GR_T 0
-#define GSR_GR_XY 9
-#define GSR_GR_NRM 11
-#define GSR_GR_OPA 14
-#define GSR_GR_RGB 15
+#define GSR_GR_NRM 9
+#define GSR_GR_OPA 12
+#define GSR_GR_RGB 13
+#define GSR_GR_XY 16
 
 static inline size_t gsr_align(size_t x) { return (x + 255) & ~size_t(255); }
 
@@ -164,11 +167,12 @@ int gsr_launch_slot_count(int D, int n_tiles, const uint32_t* ranges, const uint
 int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* covered, const uint32_t* inst_row,
                           const float* splat, const uint32_t* touch, const uint32_t* slot_off, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
-                          const float* feat, const uint32_t* point_list, float* feat_rows, hipStream_t s);
-int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint32_t* offs, const uint32_t* slot_off,
+                          float* grad_xy, int N, const uint32_t* offs, uint32_t* row_begin, const float* feat,
+                          const uint32_t* point_list, float* feat_rows, hipStream_t s);
+int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint32_t* row_begin,
                                 const float* feat_rows, float* dL_dcolors, hipStream_t s);
-int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* offs, const uint32_t* slot_off,
-                           const float* grad_rows, float* row_sums, hipStream_t s);
+int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* row_begin,
+                           const float* grad_rows, const float* grad_xy, float* row_sums, hipStream_t s);
 int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int32_t* radii,
                               const float* splat, const uint32_t* clamped, const float* row_sums,
                               const float* color_jac /* [N,9] or NULL */, const GsrGrads& out, hipStream_t s);

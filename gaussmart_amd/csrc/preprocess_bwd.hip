@@ -36,22 +36,47 @@ struct PreBwdParams {
 
 // 16 lanes (one DPP row) per Gaussian, in depth-rank order.  Instance e owns the dense gradient rows
 // [slot_off[e], slot_off[e + 1]) and a Gaussian's instances are consecutive in emission order, so ALL rows of
-// a Gaussian are one contiguous run of 80-byte rows.  Lanes 0..14 read it three rows (240 contiguous bytes) per
-// round, four rounds in flight: lane s always handles 16-byte column group s % 5 of row 3k + s / 5.  Two DPP
-// shifts then add the three lanes that share a column group.  Fixed order => bitwise reproducible gradients.
+// the Gaussian of depth rank r are one contiguous run starting at row_begin[r] = slot_off[offs[r]] (written by the
+// render_bwd launch, render_bwd_shared.h) -- a run of 64-byte rows (and one run of 8-byte xy pairs in the second array).  The 16 lanes
+// read four rows (256 contiguous, 64-byte aligned bytes) per round, four rounds in flight: lane s always handles 16-byte
+// column group s % 4 of row 4k + s / 4.  Three DPP shifts then add the four lanes that share a column group; the xy
+// pairs are read one row per lane and summed over the 16 lanes.  Fixed order => bitwise reproducible gradients.
 //
 // Load balance: a splat that fills the screen owns tens of thousands of rows (one per 4x4 block it was blended into),
 // and 16 lanes walking them 12 at a time would hold the whole kernel hostage (measured: 1 M splats of 24 px mean radius,
 // after 400 training steps reduce_rows 0.35 -> 5.6 ms per launch).  A Gaussian with more than RR_BIG rows is therefore
 // only NOTED by its 16 lanes (LDS list, at most 16 per workgroup) and summed afterwards by the WHOLE 256-thread
-// workgroup: group g takes rounds g, g + 16, ... of three rows, the 16 partial sums are combined through LDS in group
+// workgroup: group g takes rounds g, g + 16, ... of four rows, the 16 partial sums are combined through LDS in group
 // order.  The assignment of rows to lanes is fixed, so gradients stay bitwise reproducible.
 #define RR_BIG 192
 #define RR_GROUPS 16
-__global__ void __launch_bounds__(256) reduce_rows_kernel(int N, const uint32_t* __restrict__ order,
-                                                          const uint32_t* __restrict__ offs,
-                                                          const uint32_t* __restrict__ slot_off,
+// sum over the 16 lanes of a DPP row, in a fixed order; the total is valid in lane 15 of the row
+__device__ __forceinline__ float rr_row_total(float v) {
+    v += dpp_move<0x111, 0xf>(v);   // row_shr:1
+    v += dpp_move<0x112, 0xf>(v);   // row_shr:2
+    v += dpp_move<0x114, 0xf>(v);   // row_shr:4
+    v += dpp_move<0x118, 0xf>(v);   // row_shr:8
+    return v;
+}
+// lanes s, s + 4, s + 8, s + 12 of a DPP row hold the same 16-byte column group of four different rows: their sum, valid
+// in lanes 12..15
+__device__ __forceinline__ float4 rr_fold_phases(const float4 acc) {
+    float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float a4 = dpp_move<0x114, 0xf>(o[c]);    // row_shr:4  (lane s receives lane s - 4)
+        const float a8 = dpp_move<0x118, 0xf>(o[c]);    // row_shr:8
+        const float a12 = dpp_move<0x11C, 0xf>(o[c]);   // row_shr:12
+        o[c] = ((o[c] + a4) + a8) + a12;
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+// XY_IN_RGB (wide payloads, render_bwd_wide.hip): dxy arrives in colour columns 0 and 1 of the rows, there is no xy array.
+template <bool XY_IN_RGB>
+__global__ void __launch_bounds__(256, 8) reduce_rows_kernel(int N, const uint32_t* __restrict__ order,
+                                                             const uint32_t* __restrict__ row_begin,
                                                           const float4* __restrict__ rows,
+                                                          const float2* __restrict__ rows_xy,
                                                           float4* __restrict__ sums) {
     __shared__ uint32_t s_big[RR_GROUPS];
     __shared__ int s_nbig;
@@ -60,66 +85,79 @@ __global__ void __launch_bounds__(256) reduce_rows_kernel(int N, const uint32_t*
     __syncthreads();
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int r = (int)(t >> 4), s16 = (int)(t & 15), group = (int)(threadIdx.x >> 4);
-    bool valid = r < N && s16 < 15;
+    bool valid = r < N;
     uint32_t s0 = 0, s1 = 0;
-    if (r < N) { s0 = slot_off[offs[r]]; s1 = slot_off[offs[r + 1]]; }
+    uint32_t dst = 0;                 // read here, beside the row range: at the store it would be one more dependent trip
+    if (r < N) { s0 = row_begin[r]; s1 = row_begin[r + 1]; dst = order[r]; }
     int n_rows = (int)(s1 - s0);
     if (n_rows > RR_BIG) {            // (uniform over the 16 lanes of the Gaussian)
         if (s16 == 0) s_big[atomicAdd(&s_nbig, 1)] = (uint32_t)r;
         valid = false;
     }
     if (!valid) n_rows = 0;
-    const int sub0 = s16 / 5;                       // 0..2: row inside the round
+    const int sub0 = s16 >> 2;                      // 0..3: row inside the round
     {
-        const float4* src = rows + (size_t)s0 * 5 + s16;
+        const float4* src = rows + (size_t)s0 * 4 + s16;
+        const float2* src_xy = rows_xy + (size_t)s0 + s16;
+        float2 xy = make_float2(0.f, 0.f);
+        if (!XY_IN_RGB && s16 < n_rows) xy = src_xy[0];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k0 = 0; 3 * k0 < n_rows; k0 += 4) {
+        for (int k0 = 0; 4 * k0 < n_rows; k0 += 4) {
             float4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (3 * (k0 + u) + sub0 < n_rows) v[u] = src[15 * (k0 + u)];
+                if (4 * (k0 + u) + sub0 < n_rows) v[u] = src[16 * (k0 + u)];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
-        // all 64 lanes reach this point.  Lanes s, s + 5, s + 10 hold the same column group.
-        float o[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float a5 = dpp_move<0x115, 0xf>(o[c]);    // row_shr:5  (lane s receives lane s - 5)
-            const float a10 = dpp_move<0x11A, 0xf>(o[c]);   // row_shr:10
-            o[c] = (o[c] + a5) + a10;
+        if (!XY_IN_RGB)
+            for (int k = 16 + s16; k < n_rows; k += 16) { const float2 w = src_xy[k - s16]; xy.x += w.x; xy.y += w.y; }
+        // all 64 lanes reach this point
+        float4 o = rr_fold_phases(acc);
+        float x_tot, y_tot;
+        if (XY_IN_RGB) {
+            x_tot = o.y; y_tot = o.z;                                  // (meaningful in lane 15: columns 12..15)
+            if (s16 == 15) o = make_float4(o.x, 0.f, 0.f, 0.f);
+        } else {
+            x_tot = rr_row_total(xy.x); y_tot = rr_row_total(xy.y);
         }
-        if (valid && s16 >= 10) sums[(size_t)order[r] * 5 + (s16 - 10)] = make_float4(o[0], o[1], o[2], o[3]);
+        if (valid && s16 >= 12) sums[(size_t)dst * 5 + (s16 - 12)] = o;
+        if (valid && s16 == 15) sums[(size_t)dst * 5 + 4] = make_float4(x_tot, y_tot, 0.f, 0.f);
     }
     __syncthreads();
     const int nbig = s_nbig;          // uniform over the workgroup; 0 for almost every workgroup of an ordinary frame
     for (int b = 0; b < nbig; ++b) {
         const uint32_t rb = s_big[b];
-        const uint32_t b0 = slot_off[offs[rb]], b1 = slot_off[offs[rb + 1]];
-        const int nr = s16 < 15 ? (int)(b1 - b0) : 0;
-        const float4* src = rows + (size_t)b0 * 5 + s16;
+        const uint32_t b0 = row_begin[rb], b1 = row_begin[rb + 1];
+        const int nr = (int)(b1 - b0);
+        const float4* src = rows + (size_t)b0 * 4 + s16;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k0 = group; 3 * k0 < nr; k0 += 4 * RR_GROUPS) {
+        for (int k0 = group; 4 * k0 < nr; k0 += 4 * RR_GROUPS) {
             float4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 const int k = k0 + u * RR_GROUPS;
-                if (3 * k + sub0 < nr) v[u] = src[(size_t)15 * k];
+                if (4 * k + sub0 < nr) v[u] = src[(size_t)16 * k];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
-        float o[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float a5 = dpp_move<0x115, 0xf>(o[c]);
-            const float a10 = dpp_move<0x11A, 0xf>(o[c]);
-            o[c] = (o[c] + a5) + a10;
+        float2 xy = make_float2(0.f, 0.f);
+        if (!XY_IN_RGB)
+            for (int k = (int)threadIdx.x; k < nr; k += 256) { const float2 w = rows_xy[(size_t)b0 + k]; xy.x += w.x; xy.y += w.y; }
+        float4 o = rr_fold_phases(acc);
+        float x_tot, y_tot;
+        if (XY_IN_RGB) {
+            x_tot = o.y; y_tot = o.z;
+            if (s16 == 15) o = make_float4(o.x, 0.f, 0.f, 0.f);
+        } else {
+            x_tot = rr_row_total(xy.x); y_tot = rr_row_total(xy.y);
         }
-        if (s16 >= 10 && s16 < 15) s_part[group][s16 - 10] = make_float4(o[0], o[1], o[2], o[3]);
+        if (s16 >= 12) s_part[group][s16 - 12] = o;
+        if (s16 == 15) s_part[group][4] = make_float4(x_tot, y_tot, 0.f, 0.f);
         __syncthreads();
         if (threadIdx.x < 5) {
             float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -133,13 +171,18 @@ __global__ void __launch_bounds__(256) reduce_rows_kernel(int N, const uint32_t*
     }
 }
 
-int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* offs, const uint32_t* slot_off,
-                           const float* grad_rows, float* row_sums, hipStream_t s) {
+int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* row_begin,
+                           const float* grad_rows, const float* grad_xy, float* row_sums, hipStream_t s) {
     if (N <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_PREPROCESS_BWD, s);
     const long long n_threads = (long long)N * 16;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, s, N, order, offs,
-                       slot_off, reinterpret_cast<const float4*>(grad_rows), reinterpret_cast<float4*>(row_sums));
+    const dim3 grid((unsigned)((n_threads + 255) / 256)), block(256);
+    const float4* rows = reinterpret_cast<const float4*>(grad_rows);
+    float4* sums = reinterpret_cast<float4*>(row_sums);
+    if (grad_xy) hipLaunchKernelGGL(reduce_rows_kernel<false>, grid, block, 0, s, N, order, row_begin, rows,
+                                    reinterpret_cast<const float2*>(grad_xy), sums);
+    else hipLaunchKernelGGL(reduce_rows_kernel<true>, grid, block, 0, s, N, order, row_begin, rows,
+                            static_cast<const float2*>(nullptr), sums);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
     // takes tile (b % 8) * per_xcd + b / 8 -- every XCD owns one contiguous band of tiles, and the records shared by
     // neighbouring tiles are fetched into ONE L2 instead of several
     const int tile_lin = (int)(blockIdx.x & 7u) * p.per_xcd + (int)(blockIdx.x >> 3);
+    rb_row_begin_job(p);
     if (tile_lin >= p.n_tiles) return;
     const int tile_y = tile_lin / p.gx, tile_x = tile_lin - tile_y * p.gx;
     const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
@@ -277,9 +278,8 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
                 // the reduction never reads a row that was not written
                 const size_t slot = (size_t)rec_slot + __popc(rec_touch & below_mask);
                 if (has) {
-                    float* row = p.grad_rows + slot * RB_ROW;
-                    row[l16 < 9 ? l16 : l16 + 2] = tot;                       // skip the two xy columns
-                    if ((l16 & 7) == 0) row[GSR_GR_XY + (l16 >> 3)] = xy;
+                    p.grad_rows[slot * RB_ROW + l16] = tot;                   // one aligned 64-byte store per row
+                    if ((l16 & 7) == 0) p.grad_xy[slot * GSR_GROW_XY + (l16 >> 3)] = xy;
                 }
             }
         }
@@ -330,8 +330,7 @@ int gsr_launch_slot_count(int D, int n_tiles, const uint32_t* ranges, const uint
 #define RF_BIG 192
 __global__ void __launch_bounds__(256) reduce_feat_rows_kernel(long long n_threads, int C4,
                                                                const uint32_t* __restrict__ order,
-                                                               const uint32_t* __restrict__ offs,
-                                                               const uint32_t* __restrict__ slot_off,
+                                                               const uint32_t* __restrict__ row_begin,
                                                                const float4* __restrict__ rows,
                                                                float4* __restrict__ out) {
     __shared__ uint32_t s_big[256];
@@ -342,16 +341,24 @@ __global__ void __launch_bounds__(256) reduce_feat_rows_kernel(long long n_threa
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_threads) {
         const int r = (int)(t / C4), q = (int)(t - (long long)r * C4);
-        const uint32_t s0 = slot_off[offs[r]], s1 = slot_off[offs[r + 1]];
+        // (row_begin[r] = slot_off[offs[r]] comes from the render_bwd launch; the destination is read here, beside the row
+        // range, and four rows are in flight per thread: the kernel is bound by its chain of dependent loads, not by bytes)
+        const uint32_t s0 = row_begin[r], s1 = row_begin[r + 1], dst = order[r];
         if (s1 - s0 > (uint32_t)RF_BIG) {
             if (q == 0) s_big[atomicAdd(&s_nbig, 1)] = (uint32_t)r;
         } else {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (uint32_t sl = s0; sl < s1; ++sl) {
-                const float4 v = rows[(size_t)sl * C4 + q];
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            for (uint32_t sl = s0; sl < s1; sl += 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (sl + u < s1) v[u] = rows[(size_t)(sl + u) * C4 + q];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
             }
-            out[(size_t)order[r] * C4 + q] = acc;
+            out[(size_t)dst * C4 + q] = acc;
         }
     }
     __syncthreads();
@@ -360,7 +367,7 @@ __global__ void __launch_bounds__(256) reduce_feat_rows_kernel(long long n_threa
     const int q = (int)threadIdx.x % C4, rl = (int)threadIdx.x / C4;
     for (int b = 0; b < nbig; ++b) {
         const uint32_t rb = s_big[b];
-        const uint32_t s0 = slot_off[offs[rb]], s1 = slot_off[offs[rb + 1]];
+        const uint32_t s0 = row_begin[rb], s1 = row_begin[rb + 1];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (rl < L)
             for (uint32_t sl = s0 + (uint32_t)rl; sl < s1; sl += (uint32_t)L) {
@@ -381,14 +388,14 @@ __global__ void __launch_bounds__(256) reduce_feat_rows_kernel(long long n_threa
     }
 }
 
-int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint32_t* offs, const uint32_t* slot_off,
+int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint32_t* row_begin,
                                 const float* feat_rows, float* dL_dcolors, hipStream_t s) {
     if (N <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_PREPROCESS_BWD, s);
     const int C4 = C / 4;
     const long long n_threads = (long long)N * C4;
     hipLaunchKernelGGL(reduce_feat_rows_kernel, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, s, n_threads, C4,
-                       order, offs, slot_off, reinterpret_cast<const float4*>(feat_rows),
+                       order, row_begin, reinterpret_cast<const float4*>(feat_rows),
                        reinterpret_cast<float4*>(dL_dcolors));
     GSR_LAUNCH_CHECK();
     return GSR_OK;
@@ -397,7 +404,8 @@ int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint3
 int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* covered, const uint32_t* inst_row,
                           const float* splat, const uint32_t* touch, const uint32_t* slot_off, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
-                          const float* feat, const uint32_t* point_list, float* feat_rows, hipStream_t s) {
+                          float* grad_xy, int N, const uint32_t* offs, uint32_t* row_begin, const float* feat,
+                          const uint32_t* point_list, float* feat_rows, hipStream_t s) {
     RenderBwdParams p;
     p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
@@ -405,7 +413,8 @@ int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32
     p.ranges = ranges; p.covered = covered; p.inst_row = inst_row; p.splat = reinterpret_cast<const float4*>(splat); p.touch = touch;
     p.slot_off = slot_off; p.bg = v.bg;
     p.final_T = final_T; p.n_contrib = n_contrib; p.dL_dcolor = dL_dcolor; p.dL_dallmap = dL_dallmap;
-    p.grad_rows = grad_rows;
+    p.grad_rows = grad_rows; p.grad_xy = grad_xy;
+    p.N = N; p.offs = offs; p.row_begin = row_begin;
     p.feat = feat; p.point_list = point_list; p.feat_rows = feat_rows; p.C = v.channels;
     if (p.gx <= 0 || gy <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_RENDER_BWD, s);

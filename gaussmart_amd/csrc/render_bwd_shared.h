@@ -21,7 +21,7 @@
 
 #define RB_BLOCK 256
 #define RB_WAVES 4
-#define RB_ROW GSR_GROW_FLOATS   // 20 floats
+#define RB_ROW GSR_GROW_MAIN   // 16 floats: one aligned 64-byte store per block and entry
 
 struct RenderBwdParams {
     int W, H, gx, n_tiles, per_xcd;
@@ -30,7 +30,9 @@ struct RenderBwdParams {
     const float4* splat; const uint32_t* touch; const uint32_t* slot_off; const float* bg;
     const float* final_T; const uint32_t* n_contrib;
     const float* dL_dcolor; const float* dL_dallmap;
-    float* grad_rows;
+    float* grad_rows; float* grad_xy;   // [R][16] and [R][2]
+    // side job of the launch (rb_row_begin_job): row_begin[r] = slot_off[offs[r]], r = 0..N, for reduce_rows
+    const uint32_t* offs; uint32_t* row_begin; int N;
     // wide payload (FEAT16 > 0): features by Gaussian id, their gradient sub-rows [(instance*4+quad)*C + ch]
     const float* feat; const uint32_t* point_list; float* feat_rows; int C;
 };
@@ -46,6 +48,15 @@ __device__ __forceinline__ uint32_t rb_pack16(int lo, int hi) {
     uint32_t r;
     asm("s_pack_ll_b32_b16 %0, %1, %2" : "=s"(r) : "s"(lo), "s"(hi));
     return r;
+}
+
+// First gradient row of every depth rank, row_begin[r] = slot_off[offs[r]] (r = 0..N): reduce_rows, the next kernel on the
+// stream, then starts its row reads after ONE dependent load instead of two (it is bound by that chain, not by bytes).
+// The render_bwd launch is the first kernel that sees the finished slot_off; every thread takes a few ranks before its
+// own work.
+__device__ __forceinline__ void rb_row_begin_job(const RenderBwdParams& p) {
+    const int n_threads = (int)(gridDim.x * blockDim.x);
+    for (int r = (int)(blockIdx.x * blockDim.x + threadIdx.x); r <= p.N; r += n_threads) p.row_begin[r] = p.slot_off[p.offs[r]];
 }
 
 // touch word of list position `pos` with the bytes of the quads that never staged that entry forced to zero

@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(RB_BLOCK, NM == 1 ? 4 : (NM == 2 ? 3 : 2)) ren
     uint32_t (*s_slot)[16] = s_slot_all[wave];
     float (*s_q)[16][16] = s_q_all[wave];
     const int tile_lin = (int)(blockIdx.x & 7u) * p.per_xcd + (int)(blockIdx.x >> 3);   // XCD-aware tile order (render_bwd.hip)
+    rb_row_begin_job(p);
     if (tile_lin >= p.n_tiles) return;
     const int tile_y = tile_lin / p.gx, tile_x = tile_lin - tile_y * p.gx;
     const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
@@ -284,18 +285,17 @@ __global__ void __launch_bounds__(RB_BLOCK, NM == 1 ? 4 : (NM == 2 ? 3 : 2)) ren
                         gT[8] = dL_dz;
                     }
                 }
-                // block-level sums of the geometry partials (16 lanes), row layout GSR_GR_* (the three colour columns of
-                // the row stay zero: a wide payload's colour gradient lives in the feature rows)
+                // block-level sums of the geometry partials (16 lanes), row layout GSR_GR_*.  A wide payload's colour
+                // gradient lives in the feature rows, so the three colour columns of the row are free: two of them carry
+                // the centre gradient dxy of the low-pass branch (reduce_rows<true> moves them to their place), and this
+                // kernel writes no second array
                 {
                     const float v16[16] = {gT[0], gT[1], gT[2], gT[3], gT[4], gT[5], gT[6], gT[7], gT[8],
-                                           gn0, gn1, gn2, gopa, 0.f, 0.f, 0.f};
+                                           gn0, gn1, gn2, gopa, gxy0, gxy1, 0.f};
                     const float tot = row_sum16_transposed(v16, l16);
-                    const float xy = row_sum2(gxy0, gxy1, l16);
                     const uint32_t slot = rec_slot + (uint32_t)__popc(rec_touch & below_mask);
                     if (has) {
-                        float* row = p.grad_rows + (size_t)slot * RB_ROW;
-                        row[l16 < 9 ? l16 : l16 + 2] = tot;
-                        if ((l16 & 7) == 0) row[GSR_GR_XY + (l16 >> 3)] = xy;
+                        p.grad_rows[(size_t)slot * RB_ROW + l16] = tot;
                         if (l16 == 0) s_slot[grp][t] = slot;
                     }
                 }
