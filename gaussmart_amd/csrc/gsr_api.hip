@@ -362,7 +362,8 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     }
     return gsr_launch_render_fwd(*view, ranges, splat, fwd_only ? nullptr : at<float>(image, IL.final_T),
                                  fwd_only ? nullptr : at<uint32_t>(image, IL.n_contrib), out->out_color, out->out_allmap,
-                                 at<uint8_t>(binning, BL.touch), at<uint32_t>(binning, BL.covered),
+                                 at<uint8_t>(binning, BL.touch), at<uint32_t>(binning, BL.covered), inst_row,
+                                 fwd_only ? nullptr : at<uint8_t>(binning, BL.slot_cnt),
                                  view->channels == 3 ? nullptr : g->colors_precomp,
                                  point_list, s);
 }
@@ -425,9 +426,7 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     size_t n_rows = n_inst * GSR_SUBROWS;       // the bound
     const uint32_t* touch = at<uint32_t>(binning, BL.touch);
     if (num_rendered > 0) {
-        rc = gsr_launch_slot_count(num_rendered, gx * gy, at<uint32_t>(binning, BL.ranges), at<uint32_t>(binning, BL.covered),
-                                   touch, at<uint32_t>(binning, BL.inst_row), slot_cnt, s);
-        if (rc != GSR_OK) return rc;
+        // (the row counts per instance were left in BINNING by the forward: render_fwd.hip, last wave of every tile)
         rc = gsr_exclusive_scan_u8(slot_cnt, slot_off, num_rendered, scan_ws, s);
         if (rc != GSR_OK) return rc;
         if (n_rows * row_bytes_each > exact_rows_threshold()) {

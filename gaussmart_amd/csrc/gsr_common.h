@@ -160,10 +160,8 @@ int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorte
                              hipStream_t s);
 int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* splat,
                           float* final_T, uint32_t* n_contrib, float* out_color,
-                          float* out_allmap, uint8_t* touch, uint32_t* covered, const float* feat, const uint32_t* point_list,
-                          hipStream_t s);
-int gsr_launch_slot_count(int D, int n_tiles, const uint32_t* ranges, const uint32_t* covered, const uint32_t* touch,
-                          const uint32_t* inst_row, uint8_t* cnt, hipStream_t s);
+                          float* out_allmap, uint8_t* touch, uint32_t* covered, const uint32_t* inst_row, uint8_t* slot_cnt,
+                          const float* feat, const uint32_t* point_list, hipStream_t s);
 int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32_t* covered, const uint32_t* inst_row,
                           const float* splat, const uint32_t* touch, const uint32_t* slot_off, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,

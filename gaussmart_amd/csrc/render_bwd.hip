@@ -290,38 +290,6 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
     }
 }
 
-// Gradient rows are dense: instance e owns rows [slot_off[e], slot_off[e + 1]), one per 4x4 block the forward
-// blended it into.  Count them per instance (touch word -> popcount, scattered to the emission index).
-// One workgroup per TILE walks the prefix of its list that at least one quad staged (covered): everything behind it was
-// occluded, has no rows, and keeps the 0 of the memset -- at D = 20 M with 300-500 entries walked per pixel that is a
-// quarter of the instances.  The counts (<= 16) are BYTES: the scatter is random at element granularity, and every
-// partially written line leaves the L2 as a full-line transaction -- into a D-byte array (L2-resident) instead of a
-// 4D-byte one.
-__global__ void __launch_bounds__(256) slot_count_kernel(int n_tiles, const uint32_t* __restrict__ ranges,
-                                                         const uint32_t* __restrict__ covered,
-                                                         const uint32_t* __restrict__ touch,
-                                                         const uint32_t* __restrict__ inst_row,
-                                                         uint8_t* __restrict__ cnt) {
-    const int tile = blockIdx.x;
-    if (tile >= n_tiles) return;
-    const uint32_t r0 = ranges[2 * tile];
-    const uint4 cov = *reinterpret_cast<const uint4*>(covered + 4 * tile);
-    const uint32_t walked = max(max(cov.x, cov.y), max(cov.z, cov.w));
-    for (uint32_t pos = threadIdx.x; pos < walked; pos += 256) {
-        const uint32_t w = rb_defined_touch(touch[(size_t)r0 + pos], pos, cov);
-        cnt[inst_row[(size_t)r0 + pos]] = (uint8_t)__popc(w);
-    }
-}
-
-int gsr_launch_slot_count(int D, int n_tiles, const uint32_t* ranges, const uint32_t* covered, const uint32_t* touch,
-                          const uint32_t* inst_row, uint8_t* cnt, hipStream_t s) {
-    if (D <= 0) return GSR_OK;
-    GsrProfileScope prof(GSR_K_SCAN, s);      // (cnt is zeroed by the caller)
-    hipLaunchKernelGGL(slot_count_kernel, dim3((unsigned)n_tiles), dim3(256), 0, s, n_tiles, ranges, covered, touch, inst_row, cnt);
-    GSR_LAUNCH_CHECK();
-    return GSR_OK;
-}
-
 // Wide payload: add a Gaussian's feature rows (same dense slots as the geometry rows) in fixed order.  One thread
 // per (depth rank, 4-channel piece); writes dL_dcolors [N,C] by Gaussian id (zeros for Gaussians with no instance).
 // As in reduce_rows, a Gaussian with more than RF_BIG rows is noted (by its piece-0 thread) and summed afterwards by the

@@ -55,6 +55,8 @@ struct RenderFwdParams {
     const float* bg;
     float* final_T; uint32_t* n_contrib; float* out_color; float* out_allmap;
     uint8_t* touch; uint32_t* covered;
+    // SAVE: the last wave of a tile to finish counts the tile's gradient rows per instance (slot_cnt[inst_row[...]])
+    const uint32_t* inst_row; uint8_t* slot_cnt;
     // wide payload (FEAT16 > 0): C = 4..64 feature channels per Gaussian instead of the RGB of the record
     const float* feat; const uint32_t* point_list; int C;
 };
@@ -104,6 +106,11 @@ __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : (FEAT16
     if (PROBE == 7) stamp_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     if (tile_lin >= p.n_tiles) return;
+    __shared__ uint32_t s_waves_done, s_cov[RF_WAVES];
+    if (SAVE) {   // the only workgroup barrier of the kernel, before anything has started
+        if (tid == 0) s_waves_done = 0;
+        __syncthreads();
+    }
     const int tile_y = tile_lin / p.gx, tile_x = tile_lin - tile_y * p.gx;
     const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
     // lanes 16g..16g+15 (one DPP row) own the 4x4 pixel block g of the quad: the backward walks per-block lists
@@ -328,6 +335,42 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
             }
         }
     }
+    // Gradient rows per instance for the backward (it used to be a launch of its own, 40 us between the loss kernels and
+    // K7): a row exists per set bit of an entry's touch word, and the word is complete once all four quads of the tile
+    // are done.  Each wave announces its end in LDS; the LAST one counts the bits of the prefix of the list that any quad
+    // staged and scatters the counts (bytes) to the emission indices -- memory work of one wave beside a chip that is
+    // busy issuing vector instructions.  Entries behind `covered` of every quad keep the zero finalize_bins wrote.
+    if (SAVE && p.slot_cnt) {
+        if (lane == 0) s_cov[wave] = (uint32_t)covered;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // touch bytes and s_cov before the announcement
+        uint32_t before = 0;
+        if (lane == 0) before = atomicAdd(&s_waves_done, 1u);
+        before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+        if (before == RF_WAVES - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t c0 = s_cov[0], c1 = s_cov[1], c2 = s_cov[2], c3 = s_cov[3];
+            const uint32_t walked = max(max(c0, c1), max(c2, c3));
+            const uint32_t* words = reinterpret_cast<const uint32_t*>(p.touch) + r0;
+            const uint32_t* rows = p.inst_row + r0;
+            for (uint32_t pos0 = 0; pos0 < walked; pos0 += 256) {
+                uint32_t w[4], e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t pos = pos0 + 64 * u + lane;
+                    w[u] = 0; e[u] = 0;
+                    if (pos < walked) { w[u] = words[pos]; e[u] = rows[pos]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t pos = pos0 + 64 * u + lane;
+                    // a quad's byte means something only below that quad's `covered`
+                    const uint32_t m = (pos < c0 ? 0x0000000Fu : 0u) | (pos < c1 ? 0x00000F00u : 0u) |
+                                       (pos < c2 ? 0x000F0000u : 0u) | (pos < c3 ? 0x0F000000u : 0u);
+                    if (pos < walked) p.slot_cnt[e[u]] = (uint8_t)__popc(w[u] & m);
+                }
+            }
+        }
+    }
 #ifdef GSR_DEV_PROBES
     if (PROBE == 7) {
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -345,14 +388,14 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
 
 int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float* splat,
                           float* final_T, uint32_t* n_contrib, float* out_color,
-                          float* out_allmap, uint8_t* touch, uint32_t* covered, const float* feat, const uint32_t* point_list,
-                          hipStream_t s) {
+                          float* out_allmap, uint8_t* touch, uint32_t* covered, const uint32_t* inst_row, uint8_t* slot_cnt,
+                          const float* feat, const uint32_t* point_list, hipStream_t s) {
     RenderFwdParams p;
     p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE; p.flags = v.flags;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
     p.ranges = ranges; p.splat = reinterpret_cast<const float4*>(splat); p.bg = v.bg;
     p.final_T = final_T; p.n_contrib = n_contrib; p.out_color = out_color; p.out_allmap = out_allmap;
-    p.touch = touch; p.covered = covered; p.feat = feat; p.point_list = point_list; p.C = v.channels;
+    p.touch = touch; p.covered = covered; p.inst_row = inst_row; p.slot_cnt = slot_cnt; p.feat = feat; p.point_list = point_list; p.C = v.channels;
     if (p.gx <= 0 || gy <= 0) return GSR_OK;
     GsrProfileScope prof(GSR_K_RENDER_FWD, s);
     p.n_tiles = p.gx * gy; p.per_xcd = (p.n_tiles + 7) / 8;
