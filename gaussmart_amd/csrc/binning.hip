@@ -610,7 +610,8 @@ int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const 
 
 // Tile ranges from the sorted tile keys (Gaussian id and emission index of every list entry are the tile sort's own two
 // value outputs; the 80-byte records themselves are NOT copied into list order: the render kernels gather them by id).
-// Also clears the per-instance row-count bytes the backward's slot_count fills in (instances nobody walked keep 0).
+// Also clears the per-instance row-count bytes the compositing kernel fills in (render_fwd.hip, last wave of a tile;
+// instances nobody walked keep 0).
 __global__ void __launch_bounds__(256) finalize_bins_kernel(int D, const uint32_t* __restrict__ tile_sorted,
                                                             uint32_t* __restrict__ ranges, uint8_t* __restrict__ slot_cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -102,7 +102,7 @@ struct GsrBinLayout {
         // The backward evaluates exactly those pairs (everything else has zero gradient).
         touch = o;      o += keep_for_backward ? gsr_align(size_t(D) * 4) : 0;
         // gradient rows per instance (emission order), one byte each: cleared by the forward's last binning kernel,
-        // filled in by the backward's slot_count for the instances somebody walked
+        // filled in by render_fwd (last wave of every tile) for the instances somebody walked
         slot_cnt = o;   o += keep_for_backward ? gsr_align(size_t(D)) : 0;
         total = o > 0 ? o : 256;
     }

@@ -4,7 +4,7 @@
 //
 // MI355X mapping: WAVE-INDEPENDENT.  A 16x16 tile is still one 256-thread workgroup (tile keys stay
 // those of the reference), but its four wave64s each own an 8x8 pixel quad and never synchronise
-// with each other -- no workgroup barrier anywhere:
+// with each other -- no workgroup barrier in the compositing (one at the very start clears an LDS counter):
 //   * a wave stages the tile's splat records 64 at a time into its PRIVATE 5 KiB LDS slice: the Gaussian
 //     ids of the list (point_list) are read two batches ahead, the 80-byte records are gathered by id
 //     one batch ahead (five 16-byte loads per lane, consecutive lanes = consecutive pieces of a record)
@@ -14,7 +14,9 @@
 //   * per surviving splat the record is read with wave-uniform (broadcast) ds_read_b128;
 //   * the wave leaves as soon as ITS 64 pixels are done (quad-level early termination);
 //   * per (instance, quad) it records one byte: "blended into at least one pixel" -- the exact set of
-//     pairs the backward has to evaluate.
+//     pairs the backward has to evaluate;
+//   * the last wave of a tile to finish counts the tile's gradient rows per instance for the backward (see the
+//     end of the kernel).
 #include <stdlib.h>
 #include "gsr_common.h"
 #include "pair_eval.h"
