@@ -30,7 +30,11 @@
 #include "render_bwd_shared.h"
 
 #ifndef RB_MIN_WAVES
-#define RB_MIN_WAVES 6   // <= 80 VGPRs; the kernel needs 72 without scratch, so seven waves per SIMD run (LDS: 7 x 20 KB)
+#define RB_MIN_WAVES 6   // <= 80 VGPRs.  Round 2's kernel needed 72 (seven waves per SIMD); with the two-array rows and the
+                         // row_begin side job it takes the 80 (six waves).  A 72-register variant -- xy address derived from
+                         // the row address, side job behind the tile's work -- runs seven waves again and is 1 % SLOWER
+                         // (K7 0.669 vs 0.662 ms, profiles/r03_notes/ab_k7_seven_waves_again.log): behind the tile the job's
+                         // two memory trips are a tail nothing overlaps, in front they hide behind the tile's own first loads
 #endif
 // (Wide per-pixel payloads have their own kernel: render_bwd_wide.hip.)
 // PROBE (developer builds only: make PROBES=1, scripts/dev_probe.py): 1 = eight more dependent VALU per iteration,

@@ -56,7 +56,18 @@ __device__ __forceinline__ uint32_t rb_pack16(int lo, int hi) {
 // own work.
 __device__ __forceinline__ void rb_row_begin_job(const RenderBwdParams& p) {
     const int n_threads = (int)(gridDim.x * blockDim.x);
-    for (int r = (int)(blockIdx.x * blockDim.x + threadIdx.x); r <= p.N; r += n_threads) p.row_begin[r] = p.slot_off[p.offs[r]];
+    // four ranks per thread and round with their two dependent loads side by side: at N = 5 M / 4,056 tiles a thread
+    // has five ranks, and one at a time they held every workgroup's start back by ten memory round trips
+    constexpr int U = 4;
+    for (long long r0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; r0 <= p.N; r0 += (long long)n_threads * U) {   // (64-bit: r0 + U n_threads may pass 2^31)
+        uint32_t o[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const long long r = r0 + (long long)u * n_threads; o[u] = r <= p.N ? p.offs[r] : 0u; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const long long r = r0 + (long long)u * n_threads; v[u] = r <= p.N ? p.slot_off[o[u]] : 0u; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const long long r = r0 + (long long)u * n_threads; if (r <= p.N) p.row_begin[r] = v[u]; }
+    }
 }
 
 // touch word of list position `pos` with the bytes of the quads that never staged that entry forced to zero

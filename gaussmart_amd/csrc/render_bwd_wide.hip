@@ -26,7 +26,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int NM>   // 16-channel tiles: C <= 16 NM
-__global__ void __launch_bounds__(RB_BLOCK, NM == 1 ? 4 : (NM == 2 ? 3 : 2)) render_bwd_wide_kernel(RenderBwdParams p) {
+__device__ __forceinline__ void render_bwd_wide_tile(const RenderBwdParams& p) {
     __shared__ float4 s_rec_all[RB_WAVES][64 * 5];
     __shared__ int s_win_all[RB_WAVES][4][16];          // [block][t] -> staged entry of the batch, -1: none
     __shared__ uint32_t s_slot_all[RB_WAVES][4][16];    // [block][t] -> gradient row of (entry, block), 0xFFFFFFFF: none
@@ -41,7 +41,6 @@ __global__ void __launch_bounds__(RB_BLOCK, NM == 1 ? 4 : (NM == 2 ? 3 : 2)) ren
     uint32_t (*s_slot)[16] = s_slot_all[wave];
     float (*s_q)[16][16] = s_q_all[wave];
     const int tile_lin = (int)(blockIdx.x & 7u) * p.per_xcd + (int)(blockIdx.x >> 3);   // XCD-aware tile order (render_bwd.hip)
-    rb_row_begin_job(p);
     if (tile_lin >= p.n_tiles) return;
     const int tile_y = tile_lin / p.gx, tile_x = tile_lin - tile_y * p.gx;
     const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
@@ -340,6 +339,12 @@ __global__ void __launch_bounds__(RB_BLOCK, NM == 1 ? 4 : (NM == 2 ? 3 : 2)) ren
         __builtin_amdgcn_wave_barrier();       // all reads of this batch precede the next batch's LDS writes
         hi = lo;
     }
+}
+
+template <int NM>
+__global__ void __launch_bounds__(RB_BLOCK, NM == 1 ? 4 : (NM == 2 ? 3 : 2)) render_bwd_wide_kernel(RenderBwdParams p) {
+    render_bwd_wide_tile<NM>(p);
+    rb_row_begin_job(p);   // behind the tile's work, where none of its registers is live (render_bwd.hip)
 }
 
 int gsr_launch_render_bwd_wide(const RenderBwdParams& p, int channels, dim3 grid, hipStream_t s) {
