@@ -175,6 +175,23 @@ int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const int
                               const float* splat, const uint32_t* clamped, const float* row_sums,
                               const float* color_jac /* [N,9] or NULL */, const GsrGrads& out, hipStream_t s);
 
+// XCD-aware tile order for the image-space stencil kernels (loss, regularizer), as in render_fwd / render_bwd: the
+// workgroups of a 1-D grid are dealt round-robin to the 8 XCDs, each with its own L2, so workgroup b takes tile
+// (b % 8) * per_xcd + b / 8 of the row-major tile list -- every XCD owns one band of tile rows, and the halo lines two
+// neighbouring tiles both read are fetched into ONE L2 (in launch order neighbours sat on different XCDs and every halo
+// line crossed the fabric twice).  Launch gsr_xcd_tile_grid(gx * gy) workgroups; false: no tile for this workgroup.
+static inline unsigned gsr_xcd_tile_grid(int n_tiles) { return 8u * (unsigned)((n_tiles + 7) / 8); }
+#ifdef __HIPCC__
+__device__ __forceinline__ bool gsr_xcd_tile(int gx, int gy, int& tile_x, int& tile_y) {
+    const int n = gx * gy, per_xcd = (n + 7) / 8;
+    const int lin = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    if (lin >= n) return false;
+    tile_y = lin / gx;
+    tile_x = lin - tile_y * gx;
+    return true;
+}
+#endif
+
 // ---------------------------------------------------------------- small device helpers
 #ifdef __HIPCC__
 // v_rcp_f32 (1 ulp); the parity budget is 1e-4 relative

@@ -65,7 +65,9 @@ __global__ void __launch_bounds__(256, 3) loss_fwd_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float sh[4][LR][LT];
     __shared__ float red[2][4];
     const int t = threadIdx.x;
-    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+    int tile_x, tile_y;
+    if (!gsr_xcd_tile((W + LT - 1) / LT, (H + LT - 1) / LT, tile_x, tile_y)) return;
+    const int x0 = tile_x * LT, y0 = tile_y * LT;
     const size_t HW = (size_t)H * W;
     float ssim_acc = 0.f, l1_acc = 0.f;
 
@@ -169,7 +171,7 @@ __global__ void __launch_bounds__(256, 3) loss_fwd_kernel(const float* __restric
     if (t < 4) {
         // the tile's sums go to the slot of its top-left 16x16 cell; the other cells it covers get zeros
         const int g16x = (W + LS_TILE - 1) / LS_TILE, g16y = (H + LS_TILE - 1) / LS_TILE;
-        const int cx = 2 * blockIdx.x + (t & 1), cy = 2 * blockIdx.y + (t >> 1);
+        const int cx = 2 * tile_x + (t & 1), cy = 2 * tile_y + (t >> 1);
         if (cx < g16x && cy < g16y) {
             const int b = cy * g16x + cx;
             partials[2 * b + 0] = t == 0 ? (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]) : 0.f;
@@ -185,7 +187,9 @@ __global__ void __launch_bounds__(256, 3) loss_bwd_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float sm[3][LR][LSTR];
     __shared__ __attribute__((aligned(16))) float sh[3][LR][LT];
     const int t = threadIdx.x;
-    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+    int tile_x, tile_y;
+    if (!gsr_xcd_tile((W + LT - 1) / LT, (H + LT - 1) / LT, tile_x, tile_y)) return;
+    const int x0 = tile_x * LT, y0 = tile_y * LT;
     const size_t HW = (size_t)H * W;
     const float gs = grad_scale[0];
     const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
@@ -280,7 +284,7 @@ extern "C" int32_t gsr_loss_forward(const float* img, const float* gt, int32_t C
     if (!img || !gt || !maps || !partials || C <= 0 || H <= 0 || W <= 0) { gsr_set_error("bad loss_forward arguments"); return GSR_E_INVALID; }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GsrProfileScope prof(GSR_K_LOSS_FWD, s);
-    dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT);
+    dim3 grid(gsr_xcd_tile_grid(((W + LT - 1) / LT) * ((H + LT - 1) / LT)));
     hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(256), 0, s, img, gt, C, H, W, maps, partials, make_window());
     GSR_LAUNCH_CHECK();
     return GSR_OK;
@@ -292,7 +296,7 @@ extern "C" int32_t gsr_loss_backward(const float* img, const float* gt, const fl
     if (!img || !gt || !maps || !grad_scale || !dimg || C <= 0 || H <= 0 || W <= 0) { gsr_set_error("bad loss_backward arguments"); return GSR_E_INVALID; }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GsrProfileScope prof(GSR_K_LOSS_BWD, s);
-    dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT);
+    dim3 grid(gsr_xcd_tile_grid(((W + LT - 1) / LT) * ((H + LT - 1) / LT)));
     hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, s, img, gt, maps, C, H, W, lambda_dssim, grad_scale, dimg, make_window());
     GSR_LAUNCH_CHECK();
     return GSR_OK;

@@ -78,7 +78,10 @@ __global__ void __launch_bounds__(256) reg_fwd_kernel(RegParams p, const float* 
     __shared__ float sd[RG_T + 2][RG_T + 3];
     __shared__ float red[2][4];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int x0 = blockIdx.x * RG_T, y0 = blockIdx.y * RG_T;
+    const int tiles_x = (p.W + RG_T - 1) / RG_T;
+    int tile_x, tile_y;
+    if (!gsr_xcd_tile(tiles_x, (p.H + RG_T - 1) / RG_T, tile_x, tile_y)) return;
+    const int x0 = tile_x * RG_T, y0 = tile_y * RG_T;
     const int x = x0 + tx, y = y0 + ty;
     const size_t HW = (size_t)p.W * p.H;
     // this pixel's own planes are requested before the staging loads are waited for
@@ -109,7 +112,7 @@ __global__ void __launch_bounds__(256) reg_fwd_kernel(RegParams p, const float* 
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = err; red[1][threadIdx.x >> 6] = dist; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int b = blockIdx.y * gridDim.x + blockIdx.x;
+        const int b = tile_y * tiles_x + tile_x;
         partials[2 * b + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
         partials[2 * b + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
@@ -122,7 +125,9 @@ __global__ void __launch_bounds__(256) reg_bwd_kernel(RegParams p, const float* 
     __shared__ float sd[RG_T + 4][RG_T + 5];          // surf_depth, halo 2
     __shared__ float sg[6][RG_T + 2][RG_T + 3];       // dL/ddx, dL/ddy of every pixel, halo 1
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int x0 = blockIdx.x * RG_T, y0 = blockIdx.y * RG_T;
+    int tile_x, tile_y;
+    if (!gsr_xcd_tile((p.W + RG_T - 1) / RG_T, (p.H + RG_T - 1) / RG_T, tile_x, tile_y)) return;
+    const int x0 = tile_x * RG_T, y0 = tile_y * RG_T;
     const size_t HW = (size_t)p.W * p.H;
     const float inv_n = 1.0f / ((float)p.W * (float)p.H);
     const float gs = grad_scale[0];
@@ -236,7 +241,7 @@ extern "C" int32_t gsr_regularizer_forward(const float* allmap, int32_t H, int32
     if (!allmap || !partials) { gsr_set_error("bad regularizer arguments"); return GSR_E_INVALID; }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GsrProfileScope prof(GSR_K_REG_FWD, s);
-    dim3 grid((W + RG_T - 1) / RG_T, (H + RG_T - 1) / RG_T);
+    dim3 grid(gsr_xcd_tile_grid(((W + RG_T - 1) / RG_T) * ((H + RG_T - 1) / RG_T)));
     hipLaunchKernelGGL(reg_fwd_kernel, grid, dim3(256), 0, s, p, allmap, partials);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
@@ -251,7 +256,7 @@ extern "C" int32_t gsr_regularizer_backward(const float* allmap, int32_t H, int3
     if (!allmap || !grad_scale || !d_allmap) { gsr_set_error("bad regularizer arguments"); return GSR_E_INVALID; }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GsrProfileScope prof(GSR_K_REG_BWD, s);
-    dim3 grid((W + RG_T - 1) / RG_T, (H + RG_T - 1) / RG_T);
+    dim3 grid(gsr_xcd_tile_grid(((W + RG_T - 1) / RG_T) * ((H + RG_T - 1) / RG_T)));
     hipLaunchKernelGGL(reg_bwd_kernel, grid, dim3(256), 0, s, p, allmap, lambda_normal, lambda_dist, grad_scale, d_allmap);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
