@@ -101,7 +101,9 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const T* __restr
 
 size_t gsr_scan_workspace_bytes(int64_t n) {
     const int64_t blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
-    return gsr_align(size_t(blocks > 2 * GSR_COUNT_PARTIALS ? blocks : 2 * GSR_COUNT_PARTIALS) * 4);   // (also holds gsr_forward's count partials)
+    // (tile totals + eight in-tile segment prefixes per tile for the rank scan; also holds gsr_forward's count partials)
+    const int64_t words = blocks * (1 + SCAN_ITEMS);
+    return gsr_align(size_t(words > 2 * GSR_COUNT_PARTIALS ? words : 2 * GSR_COUNT_PARTIALS) * 4);
 }
 
 template <typename T>
@@ -493,16 +495,17 @@ int gsr_launch_count_partials(const uint32_t* counts, int N, unsigned long long*
     return GSR_OK;
 }
 
-// Tile rects in depth-rank order: ONE gather by Gaussian id; the scan of the counts and the emission below then
-// read everything coalesced (before, the scan gathered tiles_touched twice and emit gathered four arrays).
-// The same kernel leaves the per-tile sums the scan of the counts starts from (its first launch, fused: a workgroup
-// owns the SCAN_TILE ranks of one scan tile).
+// Tile rects in depth-rank order: ONE gather by Gaussian id; the emission below then reads everything coalesced.
+// The same kernel prepares the exclusive scan of the instance counts (rect width x height) that the emission finishes
+// itself: a workgroup owns the SCAN_TILE ranks of one scan tile and leaves the tile's total and, for each of its
+// SCAN_ITEMS segments of SCAN_BLOCK consecutive ranks (= one emission workgroup), the count of the segments before it
+// inside the tile.  (Round 3: this used to be followed by a scan launch that wrote `offs` and a count array.)
 __global__ void __launch_bounds__(SCAN_BLOCK) rank_gather_kernel(int N, const uint32_t* __restrict__ order,
                                                                  const uint2* __restrict__ tile_rect,
                                                                  uint2* __restrict__ rank_rect,
-                                                                 uint32_t* __restrict__ rank_cnt,
-                                                                 uint32_t* __restrict__ partial) {
-    __shared__ uint32_t wt[SCAN_BLOCK / 64];
+                                                                 uint32_t* __restrict__ partial,
+                                                                 uint32_t* __restrict__ seg_before) {
+    __shared__ uint32_t wt[SCAN_ITEMS][SCAN_BLOCK / 64];
     const int base = blockIdx.x * SCAN_TILE + threadIdx.x;
     uint32_t g[SCAN_ITEMS];
     uint2 R[SCAN_ITEMS];
@@ -510,40 +513,40 @@ __global__ void __launch_bounds__(SCAN_BLOCK) rank_gather_kernel(int N, const ui
     for (int i = 0; i < SCAN_ITEMS; ++i) g[i] = base + i * SCAN_BLOCK < N ? order[base + i * SCAN_BLOCK] : 0u;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) R[i] = base + i * SCAN_BLOCK < N ? tile_rect[g[i]] : make_uint2(0u, 0u);
-    uint32_t sum = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
+    for (int i = 0; i < SCAN_ITEMS; ++i) {      // item i of every thread = segment i of the tile
         const int r = base + i * SCAN_BLOCK;
+        uint32_t c = 0;
         if (r < N) {
-            const uint32_t c = (R[i].y & 0xFFFFu) * (R[i].y >> 16);
+            c = (R[i].y & 0xFFFFu) * (R[i].y >> 16);
             rank_rect[r] = R[i];
-            rank_cnt[r] = c;
-            sum += c;
         }
-    }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
-    if ((threadIdx.x & 63) == 0) wt[threadIdx.x >> 6] = sum;
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+        if ((threadIdx.x & 63) == 0) wt[i][threadIdx.x >> 6] = c;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = wt[0] + wt[1] + wt[2] + wt[3];
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            seg_before[blockIdx.x * SCAN_ITEMS + i] = run;
+            run += (wt[i][0] + wt[i][1]) + (wt[i][2] + wt[i][3]);
+        }
+        partial[blockIdx.x] = run;
+    }
 }
 
-// rank_rect / rank_cnt in depth-rank order, then offs = exclusive scan of rank_cnt (offs[N] = total); scan_ws as for
-// gsr_exclusive_scan_u32
-int gsr_launch_rank_gather_scan(int N, const uint32_t* order, const uint2* tile_rect, uint2* rank_rect, uint32_t* rank_cnt,
-                                uint32_t* offs, void* scan_ws, hipStream_t s) {
+// rank_rect in depth-rank order + the scan partials of the instance counts (scan_ws: gsr_scan_workspace_bytes(N));
+// gsr_launch_emit finishes the scan and writes offs
+int gsr_launch_rank_gather_scan(int N, const uint32_t* order, const uint2* tile_rect, uint2* rank_rect, void* scan_ws,
+                                hipStream_t s) {
     if (N <= 0) return GSR_OK;
     uint32_t* partial = static_cast<uint32_t*>(scan_ws);
     const int blocks = (N + SCAN_TILE - 1) / SCAN_TILE;
-    {
-        GsrProfileScope prof(GSR_K_EMIT, s);
-        hipLaunchKernelGGL(rank_gather_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, s, N, order, tile_rect, rank_rect, rank_cnt, partial);
-    }
-    {
-        GsrProfileScope prof(GSR_K_SCAN, s);
-        hipLaunchKernelGGL(scan_apply_kernel<uint32_t>, dim3(blocks), dim3(SCAN_BLOCK), 0, s, rank_cnt, (const uint32_t*)nullptr,
-                           partial, offs, (int64_t)N);
-    }
+    GsrProfileScope prof(GSR_K_EMIT, s);
+    hipLaunchKernelGGL(rank_gather_kernel, dim3(blocks), dim3(SCAN_BLOCK), 0, s, N, order, tile_rect, rank_rect, partial,
+                       partial + blocks);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }
@@ -552,36 +555,57 @@ int gsr_launch_rank_gather_scan(int N, const uint32_t* order, const uint2* tile_
 // range.  Lane k parks rank k's (first output index, Gaussian id, tile rect) in LDS; then the 64 lanes fill the
 // range 64 outputs at a time, each finding its owner by binary search over the 64 first-indices -- the two
 // output streams are written fully coalesced however unequal the rects are.
+// The first output index of a rank is the exclusive scan of the instance counts, finished here: totals of the scan
+// tiles before this workgroup's (a few hundred words, summed by the workgroup) + the segments before it inside its
+// tile (rank_gather_kernel) + a scan over the workgroup's own 256 counts; offs[0..N] is written for the backward.
 // (Also clears two small arrays later kernels of the frame need zeroed -- the tile ranges and the tile sort's supergroup
 // table -- instead of a memset launch each.)
-__global__ void __launch_bounds__(256) emit_instances_kernel(int N, int gx,
+__global__ void __launch_bounds__(SCAN_BLOCK) emit_instances_kernel(int N, int gx,
                                                              const uint32_t* __restrict__ order,
-                                                             const uint32_t* __restrict__ offs,
+                                                             const uint32_t* __restrict__ partial,
+                                                             const uint32_t* __restrict__ seg_before,
+                                                             uint32_t* __restrict__ offs,
                                                              const uint2* __restrict__ rank_rect,
                                                              uint32_t* __restrict__ tile_keys,
                                                              uint32_t* __restrict__ emit_gid,
                                                              uint32_t* __restrict__ zero_a, int words_a,
                                                              uint32_t* __restrict__ zero_b, int words_b) {
     __shared__ uint32_t s_off[4][64], s_gid[4][64], s_xy[4][64], s_w[4][64];
+    __shared__ uint32_t wt[SCAN_BLOCK / 64];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < words_a; i += gridDim.x * 256) zero_a[i] = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < words_b; i += gridDim.x * 256) zero_b[i] = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;   // depth rank
-    uint32_t off = 0xFFFFFFFFu, g = 0, xy = 0, w = 1;
+    uint32_t g = 0, xy = 0, w = 1, cnt = 0;
     if (r < N) {
         g = order[r];
-        off = offs[r];
         const uint2 R = rank_rect[r];
         xy = R.x;
         w = max(1u, R.y & 0xFFFFu);
+        cnt = (R.y & 0xFFFFu) * (R.y >> 16);
+    }
+    // exclusive scan of the counts: scan tiles before mine + segments before mine in my tile + ranks before mine here
+    const int my_tile = blockIdx.x / SCAN_ITEMS;
+    uint32_t pre = 0;
+    for (int j = threadIdx.x; j < my_tile; j += SCAN_BLOCK) pre += partial[j];
+    uint32_t tiles_before, total_unused;
+    (void)block_excl_scan(pre, tiles_before, wt);
+    const uint32_t first = tiles_before + seg_before[blockIdx.x];
+    const uint32_t begin_of_rank = first + block_excl_scan(cnt, total_unused, wt);
+    uint32_t off = 0xFFFFFFFFu;
+    if (r < N) {
+        off = begin_of_rank;
+        offs[r] = off;
+        if (r == N - 1) offs[N] = off + cnt;
     }
     s_off[wave][lane] = off; s_gid[wave][lane] = g; s_xy[wave][lane] = xy; s_w[wave][lane] = w;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int wave_first = blockIdx.x * blockDim.x + wave * 64;
     if (wave_first >= N) return;
-    const int wave_last = min(N, wave_first + 64);                  // exclusive
-    const uint32_t begin = offs[wave_first], end = offs[wave_last]; // offs has N + 1 entries
+    const int n_here = min(64, N - wave_first);
+    const uint32_t begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+    const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)(off + cnt), n_here - 1);
     for (uint32_t o = begin + lane; o < end; o += 64) {
         // owner = last rank k of the wave with s_off[k] <= o (ranks without instances share their successor's
         // first index, so "last" skips them; lanes beyond N hold 0xFFFFFFFF)
@@ -596,14 +620,17 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int N, int gx,
     }
 }
 
-int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const uint32_t* offs,
+int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const void* scan_ws, uint32_t* offs,
                     const uint2* rank_rect, uint32_t* tile_keys, uint32_t* emit_gid,
                     uint32_t* zero_a, size_t words_a, uint32_t* zero_b, size_t words_b, hipStream_t s) {
     if (N <= 0) return GSR_OK;
     (void)grid_y;
     GsrProfileScope prof(GSR_K_EMIT, s);
-    hipLaunchKernelGGL(emit_instances_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, grid_x,
-                       order, offs, rank_rect, tile_keys, emit_gid, zero_a, (int)words_a, zero_b, (int)words_b);
+    const uint32_t* partial = static_cast<const uint32_t*>(scan_ws);
+    const int tiles = (N + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(emit_instances_kernel, dim3((N + SCAN_BLOCK - 1) / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, s, N, grid_x,
+                       order, partial, partial + tiles, offs, rank_rect, tile_keys, emit_gid, zero_a, (int)words_a, zero_b,
+                       (int)words_b);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

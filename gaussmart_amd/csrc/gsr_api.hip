@@ -240,7 +240,6 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
     uint32_t* order = at<uint32_t>(geom, GL.order);     // kept for the backward's row reduction
     uint32_t* offs = at<uint32_t>(geom, GL.offs);
     // after the depth sort its double buffers are free: they hold the rank-ordered tile rects and counts
-    uint32_t* rank_cnt = keys_tmp;
     uint2* rank_rect = reinterpret_cast<uint2*>(scratch + 2 * nb);   // 2 nb: vals_tmp + the 4th block
     void* sort_ws = scratch + 4 * nb;
     void* scan_ws = static_cast<char*>(sort_ws) + sort_ws_n;
@@ -302,7 +301,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
             rc = gsr_radix_sort_pairs(depth_key, nullptr, keys_sorted, order, keys_tmp, vals_tmp, N, 0, 32, sort_ws, s,
                                       nullptr, nullptr, nullptr, /*table_zeroed=*/true);
         if (e2 == hipSuccess && rc == GSR_OK)
-            rc = gsr_launch_rank_gather_scan(N, order, tile_rect, rank_rect, rank_cnt, offs, scan_ws, s);
+            rc = gsr_launch_rank_gather_scan(N, order, tile_rect, rank_rect, scan_ws, s);
         hipError_t e3 = e2 == hipSuccess ? hipEventSynchronize(ev) : e2;   // the one host wait of the forward
         GSR_HIP_CHECK(e3);
         if (rc != GSR_OK) return rc;
@@ -337,7 +336,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         void* sort_ws2 = sc2 + 8 * db;
         uint32_t* zero_d = nullptr; size_t zero_d_words = 0;
         gsr_sort_zero_region(sort_ws2, D, &zero_d, &zero_d_words);
-        rc = gsr_launch_emit(N, gx, gy, order, offs, rank_rect, tile_keys, emit_gid, ranges, size_t(n_tiles) * 2,
+        rc = gsr_launch_emit(N, gx, gy, order, scan_ws, offs, rank_rect, tile_keys, emit_gid, ranges, size_t(n_tiles) * 2,
                              zero_d, zero_d_words, s);
         if (rc != GSR_OK) return rc;
         // values = emission indices 0..D-1: the sort generates them itself (vals_in = NULL); the Gaussian ids travel as a
@@ -350,6 +349,7 @@ extern "C" int32_t gsr_forward(const GsrView* view, const GsrGaussians* g, GsrFo
         if (rc != GSR_OK) return rc;
     } else {
         GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, size_t(n_tiles) * 8, s));
+        GSR_HIP_CHECK(hipMemsetAsync(offs, 0, size_t(N + 1) * 4, s));     // (the emission, which writes them, did not run)
     }
 
     if (color_join.armed) {       // the colour pass has been running on the second stream: join it here

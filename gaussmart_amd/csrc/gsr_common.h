@@ -151,9 +151,9 @@ bool gsr_color_jac_available(const GsrView& v, const GsrGaussians& g);
 // (`partial` may be device-mapped host memory; `zero`: words this kernel also clears, e.g. gsr_sort_zero_region)
 int gsr_launch_count_partials(const uint32_t* counts, int N, unsigned long long* partial, int* n_partial,
                               uint32_t* zero, size_t zero_words, hipStream_t s);
-int gsr_launch_rank_gather_scan(int N, const uint32_t* order, const uint2* tile_rect, uint2* rank_rect, uint32_t* rank_cnt,
-                                uint32_t* offs, void* scan_ws, hipStream_t s);
-int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const uint32_t* offs,
+int gsr_launch_rank_gather_scan(int N, const uint32_t* order, const uint2* tile_rect, uint2* rank_rect, void* scan_ws,
+                                hipStream_t s);
+int gsr_launch_emit(int N, int grid_x, int grid_y, const uint32_t* order, const void* scan_ws, uint32_t* offs,
                     const uint2* rank_rect, uint32_t* tile_keys, uint32_t* emit_gid,
                     uint32_t* zero_a, size_t words_a, uint32_t* zero_b, size_t words_b, hipStream_t s);
 int gsr_launch_finalize_bins(int D, int n_tiles, const uint32_t* tile_keys_sorted, uint32_t* ranges, uint8_t* slot_cnt,
