@@ -15,7 +15,7 @@ struct GsrPair {
 };
 
 // Returns false when the pair is skipped before the transmittance test.
-// The rare rejects (degenerate intersection, depth behind the near plane, positive power) are
+// The rare rejects (degenerate intersection, depth behind the near plane) are
 // folded into ONE predicate instead of early exits: on a wave that saves three exec-mask
 // save/branch/restore sequences per splat, and a lane that fails an early test is invalid whatever
 // garbage its later values hold, so the decisions are exactly those of the sequential tests.
@@ -38,8 +38,9 @@ __device__ __forceinline__ bool gsr_pair_eval(float pxf, float pyf, const float4
     const float rho = fminf(rho3d, rho2d);
     o.depth = o.use3d ? fmaf(o.sx, Twx, fmaf(o.sy, Twy, Twz)) : Twz;
     valid = valid && !(o.depth < GSR_NEAR_N);
+    // (the reference's `power > 0` reject cannot fire here: rho is the smaller of two sums of squares -- fminf drops a NaN --
+    // so the power is never positive, and the test would only cost a compare per pair)
     const float power = -0.5f * rho;
-    valid = valid && !(power > 0.0f);
     o.G = __expf(power);
     o.araw = opa * o.G;
     o.alpha = fminf(GSR_ALPHA_MAX, o.araw);
