@@ -48,6 +48,28 @@ def test_forward_backward_vs_oracle(gpu_device, depth_ratio, ln, ld):
         assert float(d.mean()) <= 2e-5 * sc + 1e-14, (c, float(d.mean()), sc)
 
 
+def test_full_frame_tile_order(gpu_device):
+    """1920x1080 (8,160 tiles of 16x16 in the XCD-aware order, band boundaries inside tile rows) against the oracle."""
+    from gaussmart_amd.fused_regularizer import surface_regularizer
+    pkg, cam = _allmap_from_render(gpu_device, n=60000, w=1920, h=1080, seed=5)
+    am = pkg["allmap"].detach()
+    amh = am.clone().requires_grad_(True)
+    loss, nm, dm = surface_regularizer(amh, cam, 0.0, 0.05, 100.0)
+    loss.backward()
+    amo = am.cpu().double().requires_grad_(True)
+    lo, nmo, dmo = R.regularizer_loss(amo, cam.world_view_transform.cpu().double(), cam.full_proj_transform.cpu().double(),
+                                      0.0, 0.05, 100.0)
+    lo.backward()
+    np.testing.assert_allclose(nm.item(), nmo.item(), rtol=2e-5)
+    np.testing.assert_allclose(dm.item(), dmo.item(), rtol=2e-5)
+    gh, go = amh.grad.cpu().double(), torch.nan_to_num(amo.grad, 0.0, 0.0, 0.0)
+    for c in range(7):
+        sc = float(go[c].abs().max())
+        d = (gh[c] - go[c]).abs()
+        assert float(d.max()) <= 2e-3 * sc + 1e-12, (c, float(d.max()), sc)
+        assert float(d.mean()) <= 2e-5 * sc + 1e-14, (c, float(d.mean()), sc)
+
+
 def test_matches_render_maps(gpu_device):
     """Same numbers as render()'s own (torch) surf_normal / rend_normal path on the device."""
     from gaussmart_amd.fused_regularizer import surface_regularizer
