@@ -91,7 +91,8 @@ def test_preprocess_parity(gpu_device, n, w, h, seed):
     assert int((dbg["clamped"].cpu()[vi] != cl[vi]).sum()) <= 2
 
 
-@pytest.mark.parametrize("n,w,h,seed", [(2000, 256, 256, 0), (5000, 640, 360, 3), (300, 33, 17, 4)])
+@pytest.mark.parametrize("n,w,h,seed", [(2000, 256, 256, 0), (5000, 640, 360, 3), (300, 33, 17, 4),
+                                        (100_003, 640, 360, 5)])     # 49 scan tiles, a ragged last emission workgroup
 def test_binning_bit_exact(gpu_device, n, w, h, seed):
     p, cam = make_scene(n, w, h, seed=seed)
     a = activate(p)
