@@ -502,6 +502,8 @@ extern "C" int32_t gsr_buffer_field(int32_t which, const char* name, int32_t N, 
         if (!strcmp(name, "inst_row")) { *offset = L.inst_row; *bytes = size_t(D) * 4; return GSR_OK; }
         if (!strcmp(name, "ranges")) { *offset = L.ranges; *bytes = size_t(gx) * gy * 8; return GSR_OK; }
         if (!strcmp(name, "covered")) { *offset = L.covered; *bytes = size_t(gx) * gy * 16; return GSR_OK; }
+        if (!strcmp(name, "touch")) { *offset = L.touch; *bytes = size_t(D) * 4; return GSR_OK; }
+        if (!strcmp(name, "row_count")) { *offset = L.slot_cnt; *bytes = size_t(D); return GSR_OK; }
     } else if (which == GSR_BUF_IMAGE) {
         const GsrImageLayout L(P);
         if (!strcmp(name, "final_T")) { *offset = L.final_T; *bytes = size_t(P) * 12; return GSR_OK; }

@@ -678,7 +678,8 @@ def rasterize_debug(means3D, opacities, shs=None, colors_precomp=None, scales=No
                             ("tiles_touched", torch.int32, (N,)), ("depth_key", torch.int32, (N,)),
                             ("order", torch.int32, (N,)), ("offs", torch.int32, (N + 1,))],
         _lib.GSR_BUF_BINNING: [("point_list", torch.int32, (D,)), ("inst_row", torch.int32, (D,)),
-                               ("ranges", torch.int32, (-1, 2)), ("covered", torch.int32, (-1, 4))],
+                               ("ranges", torch.int32, (-1, 2)), ("covered", torch.int32, (-1, 4)),
+                               ("touch", torch.int32, (D,)), ("row_count", torch.uint8, (D,))],
         _lib.GSR_BUF_IMAGE: [("final_T", torch.float32, (3, H, W)), ("n_contrib", torch.int32, (2, H, W))],
     }
     for which, fields in spec.items():
@@ -687,7 +688,7 @@ def rasterize_debug(means3D, opacities, shs=None, colors_precomp=None, scales=No
             try:
                 off, nbytes = _lib.buffer_field(which, name, N, D, W, H)
             except _lib.GsrError:
-                if name != "covered":      # (an older build of the library, loaded through GSR_LIB_PATH for an A/B run)
+                if name not in ("covered", "touch", "row_count"):   # (an older library build, loaded through GSR_LIB_PATH for an A/B run)
                     raise
                 continue
             res[name] = buf[off:off + nbytes].view(dt).reshape(shape) if nbytes else \

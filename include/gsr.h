@@ -189,7 +189,10 @@ int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int32_t num_ren
  * field inside buffer `which` for a problem of N Gaussians, D instances, W x H pixels.
  * Names: GEOM: "splat" f32[N,20], "clamped" u32[N], "tiles_touched" u32[N], "depth_key" u32[N],
  *        "order" u32[N] (depth rank -> Gaussian id), "offs" u32[N+1] (depth rank -> first emission index);
- *        BINNING: "point_list" u32[D], "inst_row" u32[D] (emission index of each list entry), "ranges" u32[tiles,2];
+ *        BINNING: "point_list" u32[D], "inst_row" u32[D] (emission index of each list entry), "ranges" u32[tiles,2],
+ *                 "covered" u32[tiles,4] (list entries each 8x8 quad staged), "touch" u32[D] (per list entry: one byte per
+ *                 quad, one bit per 4x4 block it was blended into; a quad's byte is defined below its `covered`),
+ *                 "row_count" u8[D] (gradient rows per instance, by emission index: left by the forward for the backward);
  *        IMAGE: "final_T" f32[3,H,W], "n_contrib" u32[2,H,W]. */
 int32_t gsr_buffer_field(int32_t which, const char* name, int32_t N, int32_t D, int32_t W,
                          int32_t H, size_t* offset, size_t* bytes);

@@ -118,6 +118,33 @@ def test_binning_bit_exact(gpu_device, n, w, h, seed):
         assert np.all(g_of_row[ib[g]:ib[g] + tt[g]] == g)
 
 
+@pytest.mark.parametrize("n,w,h,seed", [(2000, 256, 256, 0), (20000, 250, 130, 1), (300, 33, 17, 4)])
+def test_gradient_row_counts_left_by_the_forward(gpu_device, n, w, h, seed):
+    """The backward's dense gradient rows are allocated from per-instance counts the compositing kernel leaves itself (the
+    last wave of every tile): count of instance e = set bits of its touch word, a quad's byte counting only below that
+    quad's `covered`; instances nobody walked keep 0.  Checked against the touch words, list entry by list entry."""
+    p, cam = make_scene(n, w, h, seed=seed)
+    dbg = _debug(activate(p), cam, gpu_device)
+    D = dbg["num_rendered"]
+    touch = dbg["touch"].cpu().numpy().astype(np.uint32)
+    rows = dbg["inst_row"].cpu().numpy().astype(np.int64)
+    ranges = dbg["ranges"].cpu().numpy().astype(np.int64)
+    cov = dbg["covered"].cpu().numpy().astype(np.int64)
+    got = dbg["row_count"].cpu().numpy().astype(np.int64)
+    want = np.zeros(D, np.int64)
+    for t in range(ranges.shape[0]):
+        r0, r1 = ranges[t]
+        pos = np.arange(r1 - r0)
+        word = touch[r0:r1].copy()
+        mask = np.zeros(r1 - r0, np.uint32)
+        for q in range(4):
+            mask |= np.where(pos < cov[t, q], np.uint32(0xF << (8 * q)), np.uint32(0))
+        word &= mask
+        want[rows[r0:r1]] = np.array([bin(int(x)).count("1") for x in word], np.int64)
+    assert D > 0 and want.sum() > 0
+    np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.parametrize("n,w,h,seed,bg", [(2000, 256, 256, 0, (0.2, 0.4, 0.6)), (3000, 250, 130, 1, (1.0, 1.0, 1.0))])
 def test_render_forward_parity(gpu_device, n, w, h, seed, bg):
     p, cam = make_scene(n, w, h, seed=seed)
