@@ -130,6 +130,11 @@ def lib():
         L.gsr_regularizer_backward.restype = C.c_int32
         L.gsr_regularizer_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float,
                                                C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        if hasattr(L, "gsr_loss_backward_finish"):        # (absent from libraries built before it existed: A/B runs)
+            L.gsr_loss_backward_finish.restype = C.c_int32
+            L.gsr_loss_backward_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                                   C.c_float, C.c_void_p, C.c_void_p]
         L.gsr_objective_finish.restype = C.c_int32
         L.gsr_objective_finish.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
                                            C.c_float, C.c_float, C.c_void_p, C.c_void_p]

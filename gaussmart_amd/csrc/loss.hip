@@ -180,15 +180,80 @@ __global__ void __launch_bounds__(256, 3) loss_fwd_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Objective finish: turns the per-block partials of loss_fwd (and optionally reg_fwd) into the
+// five scalars of the training objective in ONE tiny launch, instead of ~20 zero-dim torch kernels:
+//   out[0] = total = (1-l) * l1 + l * (1 - ssim) + ln * normal + ld * dist
+//   out[1] = l1, out[2] = ssim, out[3] = mean normal error, out[4] = mean distortion
+// Fixed summation order (single workgroup, strided chunks, tree) => reproducible loss value.
+struct FinishArgs {
+    const float* pl; int n_pl; float inv_n_img;       // loss partials (pairs), their count, 1 / (C H W)
+    const float* pr; int n_pr; float inv_n_pix;       // regularizer partials (pairs) or NULL / 0, 1 / (H W)
+    float lambda_dssim, lambda_normal, lambda_dist;
+    float* out;                                       // f32[5]; NULL: nothing to finish
+};
+
+// one 256-thread workgroup
+__device__ __forceinline__ void objective_finish_body(const FinishArgs& f) {
+    const float* __restrict__ pl = f.pl; const float* __restrict__ pr = f.pr;
+    const int n_pl = f.n_pl, n_pr = f.n_pr;
+    const float inv_n_img = f.inv_n_img, inv_n_pix = f.inv_n_pix;
+    const float lambda_dssim = f.lambda_dssim, lambda_normal = f.lambda_normal, lambda_dist = f.lambda_dist;
+    float* __restrict__ out = f.out;
+    __shared__ float red[4][256];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    // eight independent 8-byte loads in flight per thread and round (one at a time made this 1-block kernel wait
+    // ~30 memory latencies in a row); the per-thread summation order is unchanged
+    const float2* pl2 = reinterpret_cast<const float2*>(pl);
+    const float2* pr2 = reinterpret_cast<const float2*>(pr);
+    for (int base = threadIdx.x; base < n_pl; base += 256 * 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = base + 256 * u; v[u] = i < n_pl ? pl2[i] : make_float2(0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s0 += v[u].x; s1 += v[u].y; }
+    }
+    for (int base = threadIdx.x; base < n_pr; base += 256 * 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = base + 256 * u; v[u] = i < n_pr ? pr2[i] : make_float2(0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s2 += v[u].x; s3 += v[u].y; }
+    }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2; red[3][threadIdx.x] = s3;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + d];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float ssim = red[0][0] * inv_n_img, l1 = red[1][0] * inv_n_img;
+        const float nrm = red[2][0] * inv_n_pix, dst = red[3][0] * inv_n_pix;
+        out[0] = (1.0f - lambda_dssim) * l1 + lambda_dssim * (1.0f - ssim) + lambda_normal * nrm + lambda_dist * dst;
+        out[1] = l1; out[2] = ssim; out[3] = nrm; out[4] = dst;
+    }
+}
+
+__global__ void __launch_bounds__(256) objective_finish_kernel(FinishArgs f) { objective_finish_body(f); }
+
 __global__ void __launch_bounds__(256, 3) loss_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
                                                        const float* __restrict__ maps, int C, int H, int W,
                                                        float lambda, const float* __restrict__ grad_scale,
-                                                       float* __restrict__ dimg, LossWindow win) {
+                                                       float* __restrict__ dimg, LossWindow win, FinishArgs fin) {
     __shared__ __attribute__((aligned(16))) float sm[3][LR][LSTR];
     __shared__ __attribute__((aligned(16))) float sh[3][LR][LT];
     const int t = threadIdx.x;
     int tile_x, tile_y;
-    if (!gsr_xcd_tile((W + LT - 1) / LT, (H + LT - 1) / LT, tile_x, tile_y)) return;
+    if (!gsr_xcd_tile((W + LT - 1) / LT, (H + LT - 1) / LT, tile_x, tile_y)) {
+        // gsr_loss_backward_finish: the launch carries one workgroup without a tile (the last one) that turns the forward's
+        // partials into the five scalars of the objective -- work this kernel does not depend on, so it rides along
+        // instead of being a launch of its own between the forward and the backward kernels
+        if (fin.out != nullptr && blockIdx.x == gridDim.x - 1) objective_finish_body(fin);
+        return;
+    }
     const int x0 = tile_x * LT, y0 = tile_y * LT;
     const size_t HW = (size_t)H * W;
     const float gs = grad_scale[0];
@@ -297,68 +362,49 @@ extern "C" int32_t gsr_loss_backward(const float* img, const float* gt, const fl
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GsrProfileScope prof(GSR_K_LOSS_BWD, s);
     dim3 grid(gsr_xcd_tile_grid(((W + LT - 1) / LT) * ((H + LT - 1) / LT)));
-    hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, s, img, gt, maps, C, H, W, lambda_dssim, grad_scale, dimg, make_window());
+    FinishArgs none{};
+    hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, s, img, gt, maps, C, H, W, lambda_dssim, grad_scale, dimg, make_window(),
+                       none);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Objective finish: turns the per-block partials of loss_fwd (and optionally reg_fwd) into the
-// five scalars of the training objective in ONE tiny launch, instead of ~20 zero-dim torch kernels:
-//   out[0] = total = (1-l) * l1 + l * (1 - ssim) + ln * normal + ld * dist
-//   out[1] = l1, out[2] = ssim, out[3] = mean normal error, out[4] = mean distortion
-// Fixed summation order (single workgroup, strided chunks, tree) => reproducible loss value.
-__global__ void __launch_bounds__(256) objective_finish_kernel(const float* __restrict__ pl, int n_pl, float inv_n_img,
-                                                               const float* __restrict__ pr, int n_pr, float inv_n_pix,
-                                                               float lambda_dssim, float lambda_normal, float lambda_dist,
-                                                               float* __restrict__ out) {
-    __shared__ float red[4][256];
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    // eight independent 8-byte loads in flight per thread and round (one at a time made this 1-block kernel wait
-    // ~30 memory latencies in a row); the per-thread summation order is unchanged
-    const float2* pl2 = reinterpret_cast<const float2*>(pl);
-    const float2* pr2 = reinterpret_cast<const float2*>(pr);
-    for (int base = threadIdx.x; base < n_pl; base += 256 * 8) {
-        float2 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = base + 256 * u; v[u] = i < n_pl ? pl2[i] : make_float2(0.f, 0.f); }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { s0 += v[u].x; s1 += v[u].y; }
+static FinishArgs make_finish(const float* loss_partials, int C, int H, int W, const float* reg_partials, float lambda_dssim,
+                              float lambda_normal, float lambda_dist, float* out5) {
+    FinishArgs f;
+    const int n = gsr_loss_num_partials(H, W) / 2;
+    f.pl = loss_partials; f.n_pl = n; f.inv_n_img = 1.0f / ((float)C * (float)H * (float)W);
+    f.pr = reg_partials; f.n_pr = reg_partials ? n : 0; f.inv_n_pix = 1.0f / ((float)H * (float)W);
+    f.lambda_dssim = lambda_dssim; f.lambda_normal = reg_partials ? lambda_normal : 0.f;
+    f.lambda_dist = reg_partials ? lambda_dist : 0.f; f.out = out5;
+    return f;
+}
+
+extern "C" int32_t gsr_loss_backward_finish(const float* img, const float* gt, const float* maps, int32_t C, int32_t H,
+                                            int32_t W, float lambda_dssim, const float* grad_scale, float* dimg,
+                                            const float* loss_partials, const float* reg_partials, float lambda_normal,
+                                            float lambda_dist, float* out5, gsr_stream_t stream_) {
+    if (!img || !gt || !maps || !grad_scale || !dimg || !loss_partials || !out5 || C <= 0 || H <= 0 || W <= 0) {
+        gsr_set_error("bad loss_backward_finish arguments");
+        return GSR_E_INVALID;
     }
-    for (int base = threadIdx.x; base < n_pr; base += 256 * 8) {
-        float2 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = base + 256 * u; v[u] = i < n_pr ? pr2[i] : make_float2(0.f, 0.f); }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { s2 += v[u].x; s3 += v[u].y; }
-    }
-    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2; red[3][threadIdx.x] = s3;
-    __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
-        if (threadIdx.x < d) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + d];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const float ssim = red[0][0] * inv_n_img, l1 = red[1][0] * inv_n_img;
-        const float nrm = red[2][0] * inv_n_pix, dst = red[3][0] * inv_n_pix;
-        out[0] = (1.0f - lambda_dssim) * l1 + lambda_dssim * (1.0f - ssim) + lambda_normal * nrm + lambda_dist * dst;
-        out[1] = l1; out[2] = ssim; out[3] = nrm; out[4] = dst;
-    }
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    GsrProfileScope prof(GSR_K_LOSS_BWD, s);
+    // one more row of eight workgroups than the tiles need: the last of them has no tile by construction
+    dim3 grid(gsr_xcd_tile_grid(((W + LT - 1) / LT) * ((H + LT - 1) / LT)) + 8u);
+    hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, s, img, gt, maps, C, H, W, lambda_dssim, grad_scale, dimg, make_window(),
+                       make_finish(loss_partials, C, H, W, reg_partials, lambda_dssim, lambda_normal, lambda_dist, out5));
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
 }
 
 extern "C" int32_t gsr_objective_finish(const float* loss_partials, int32_t C, int32_t H, int32_t W,
                                         const float* reg_partials, float lambda_dssim, float lambda_normal,
                                         float lambda_dist, float* out5, gsr_stream_t stream_) {
     if (!loss_partials || !out5 || C <= 0 || H <= 0 || W <= 0) { gsr_set_error("bad objective_finish arguments"); return GSR_E_INVALID; }
-    const int n = gsr_loss_num_partials(H, W) / 2;
     hipStream_t s = static_cast<hipStream_t>(stream_);
-    hipLaunchKernelGGL(objective_finish_kernel, dim3(1), dim3(256), 0, s, loss_partials, n,
-                       1.0f / ((float)C * (float)H * (float)W), reg_partials, reg_partials ? n : 0,
-                       1.0f / ((float)H * (float)W), lambda_dssim, reg_partials ? lambda_normal : 0.f,
-                       reg_partials ? lambda_dist : 0.f, out5);
+    hipLaunchKernelGGL(objective_finish_kernel, dim3(1), dim3(256), 0, s,
+                       make_finish(loss_partials, C, H, W, reg_partials, lambda_dssim, lambda_normal, lambda_dist, out5));
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

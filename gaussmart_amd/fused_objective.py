@@ -19,7 +19,7 @@ from .fused_regularizer import camera_kinv
 
 class _Objective(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image, allmap, gt, kinv, lambda_dssim, lambda_normal, lambda_dist, depth_ratio):
+    def forward(ctx, image, allmap, gt, kinv, lambda_dssim, lambda_normal, lambda_dist, depth_ratio, defer_value=False):
         L = _lib.lib()
         if image.device.type != "cuda":
             raise _lib.GsrError("training_objective needs tensors on a HIP device (torch 'cuda'); there is no CPU path")
@@ -42,9 +42,15 @@ class _Objective(torch.autograd.Function):
                 _lib.check(L.gsr_regularizer_forward(C.c_void_p(am.data_ptr()), H, W, kinv, float(depth_ratio),
                                                      C.c_void_p(partials[1].data_ptr()), stream))
                 reg_ptr = C.c_void_p(partials[1].data_ptr())
-            _lib.check(L.gsr_objective_finish(C.c_void_p(partials[0].data_ptr()), Cn, H, W, reg_ptr,
-                                              float(lambda_dssim), float(lambda_normal), float(lambda_dist),
-                                              C.c_void_p(out.data_ptr()), stream))
+            # defer_value (training_step: the backward follows at once and nobody reads the value in between): the five
+            # scalars are computed by a workgroup riding along with the backward's first kernel (gsr_loss_backward_finish)
+            ctx.deferred = None
+            if defer_value and ctx.needs_input_grad[0] and hasattr(L, "gsr_loss_backward_finish"):
+                ctx.deferred = (partials, out, use_reg)
+            else:
+                _lib.check(L.gsr_objective_finish(C.c_void_p(partials[0].data_ptr()), Cn, H, W, reg_ptr,
+                                                  float(lambda_dssim), float(lambda_normal), float(lambda_dist),
+                                                  C.c_void_p(out.data_ptr()), stream))
         ctx.use_reg = use_reg
         ctx.cfg = (kinv, float(lambda_dssim), float(lambda_normal), float(lambda_dist), float(depth_ratio))
         ctx.has_allmap = allmap is not None
@@ -60,7 +66,7 @@ class _Objective(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_parts):
         if g_total is None:
-            return (None,) * 8
+            return (None,) * 9
         L = _lib.lib()
         saved = ctx.saved_tensors
         img, tgt, maps = saved[0], saved[1], saved[2]
@@ -72,20 +78,31 @@ class _Objective(torch.autograd.Function):
             scale = g_total.detach().float().reshape(1).contiguous()
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             dimg = torch.empty_like(img)
-            _lib.check(L.gsr_loss_backward(C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()), C.c_void_p(maps.data_ptr()),
-                                           Cn, H, W, ld, C.c_void_p(scale.data_ptr()), C.c_void_p(dimg.data_ptr()), stream))
+            if ctx.deferred is not None:
+                partials, out, with_reg = ctx.deferred
+                ctx.deferred = None
+                _lib.check(L.gsr_loss_backward_finish(
+                    C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()), C.c_void_p(maps.data_ptr()), Cn, H, W, ld,
+                    C.c_void_p(scale.data_ptr()), C.c_void_p(dimg.data_ptr()), C.c_void_p(partials[0].data_ptr()),
+                    C.c_void_p(partials[1].data_ptr()) if with_reg else None, ln, ldist, C.c_void_p(out.data_ptr()), stream))
+            else:
+                _lib.check(L.gsr_loss_backward(C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()),
+                                               C.c_void_p(maps.data_ptr()), Cn, H, W, ld, C.c_void_p(scale.data_ptr()),
+                                               C.c_void_p(dimg.data_ptr()), stream))
             if ctx.use_reg:
                 am = saved[3]
                 dam = torch.empty_like(am)
                 _lib.check(L.gsr_regularizer_backward(C.c_void_p(am.data_ptr()), H, W, kinv, ratio, ln, ldist,
                                                       C.c_void_p(scale.data_ptr()), C.c_void_p(dam.data_ptr()), stream))
-        return dimg, dam, None, None, None, None, None, None
+        return dimg, dam, None, None, None, None, None, None, None
 
 
 def training_objective(image, allmap, gt, viewpoint_camera, lambda_dssim=0.2, lambda_normal=0.0, lambda_dist=0.0,
-                       depth_ratio=0.0):
-    """-> (total, parts) with parts = [l1, ssim, mean normal error, mean distortion] (device tensor)."""
+                       depth_ratio=0.0, defer_value=False):
+    """-> (total, parts) with parts = [l1, ssim, mean normal error, mean distortion] (device tensor).
+    `defer_value`: for callers that call backward() right away and read the values only afterwards -- the five scalars
+    are then written during the backward (one launch less in the iteration); before it they are undefined."""
     use_reg = allmap is not None and (lambda_normal > 0.0 or lambda_dist > 0.0)
     kinv = camera_kinv(viewpoint_camera) if use_reg else None
     return _Objective.apply(image, allmap if use_reg else None, gt, kinv, lambda_dssim, lambda_normal, lambda_dist,
-                            depth_ratio)
+                            depth_ratio, bool(defer_value))

@@ -42,7 +42,7 @@ def _unit_gradient(t):
     return one
 
 
-def training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam=None, pipe=None):
+def training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam=None, pipe=None, defer_value=False):
     """train.py:113-143.  On a HIP device the whole objective (L1 + SSIM + surface regularizers) is
     one fused autograd node (gaussmart_amd/fused_objective.py); on the host (CPU plumbing tests)
     the stock torch formulation of the reference is used on the maps render() derived."""
@@ -51,7 +51,7 @@ def training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam=None, pi
     lambda_dist = opt.lambda_dist if iteration > 3000 else 0.0
     if "rend_normal" not in render_pkg:
         total, parts = training_objective(image, render_pkg["allmap"], gt_image, viewpoint_cam, opt.lambda_dssim,
-                                          lambda_normal, lambda_dist, pipe.depth_ratio)
+                                          lambda_normal, lambda_dist, pipe.depth_ratio, defer_value=defer_value)
         l1, ssim_v = parts[0], parts[1]
         return total, {"l1": l1, "ssim": ssim_v, "normal_mean": parts[2], "dist_mean": parts[3], "loss": total.detach()}
     loss, Ll1 = photometric(image, gt_image, opt.lambda_dssim)
@@ -99,7 +99,9 @@ def training_step(gaussians, viewpoint_cam, gt_image, opt, pipe, background, ite
         render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=False, factored_sh_grad=True)
     else:
         render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=not on_device)
-    total, parts = training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam, pipe)
+    # (the backward follows at once: the loss scalars are written by a workgroup of its first kernel, not by a launch of
+    # their own -- nobody reads them before this function returns)
+    total, parts = training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam, pipe, defer_value=True)
     total.backward(gradient=_unit_gradient(total))   # cached: saves the ones_like() fill of every step
     rec = take_color_grad(gaussians._xyz) if factored else None
     if factored:

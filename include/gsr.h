@@ -246,6 +246,15 @@ int32_t gsr_objective_finish(const float* loss_partials, int32_t C, int32_t H, i
                              const float* reg_partials, float lambda_dssim, float lambda_normal,
                              float lambda_dist, float* out5, gsr_stream_t stream);
 
+/* gsr_loss_backward and gsr_objective_finish as ONE launch: the backward kernel does not depend on the five scalars, so the
+ * workgroup that computes them rides along with it (one kernel boundary less between the forward and the backward of the
+ * objective).  For callers that run the backward right after the forward and read the loss value only afterwards: out5 is
+ * written by THIS call, not by the forward.  Same values as the two separate calls. */
+int32_t gsr_loss_backward_finish(const float* img, const float* gt, const float* maps, int32_t C, int32_t H,
+                                 int32_t W, float lambda_dssim, const float* grad_scale, float* dimg,
+                                 const float* loss_partials, const float* reg_partials, float lambda_normal,
+                                 float lambda_dist, float* out5, gsr_stream_t stream);
+
 /* Dense Adam step over up to 8 parameter tensors in one launch; the update of
  * torch.optim.Adam as the reference configures it (scene/gaussian_model.py:282-295).  All arrays
  * are HOST arrays of length `count`; the pointers inside are device f32 buffers of numel[i]

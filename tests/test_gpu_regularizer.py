@@ -123,3 +123,23 @@ def test_fused_objective_vs_oracles(gpu_device, ln, ld):
             assert float((ga[c] - gao[c]).abs().max()) <= 2e-3 * sc + 1e-12
     else:
         assert ah.grad is None or float(ah.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("ln,ld", [(0.05, 100.0), (0.0, 0.0)])
+def test_objective_value_written_during_the_backward(gpu_device, ln, ld):
+    """training_objective(defer_value=True): the five scalars come from a workgroup riding along with the backward's first
+    kernel (gsr_loss_backward_finish) instead of a launch of their own -- same values, same gradients, bit for bit."""
+    from gaussmart_amd.fused_objective import training_objective
+    pkg, cam = _allmap_from_render(gpu_device, seed=2)
+    img, am = pkg["render"].detach(), pkg["allmap"].detach()
+    gt = (img * 0.9 + 0.05).clamp(0, 1).contiguous()
+    res = []
+    for defer in (False, True):
+        a, b = img.clone().requires_grad_(True), am.clone().requires_grad_(True)
+        total, parts = training_objective(a, b, gt, cam, 0.2, ln, ld, 0.0, defer_value=defer)
+        total.backward()
+        torch.cuda.synchronize()
+        res.append((total.detach().clone(), parts.clone(), a.grad.clone(), None if b.grad is None else b.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert (res[0][3] is None) == (res[1][3] is None) and (res[0][3] is None or torch.equal(res[0][3], res[1][3]))
+    assert float(res[1][0]) > 0.0
