@@ -66,6 +66,12 @@ class GsrGrads(C.Structure):
                 ("dL_drotations", C.c_void_p), ("dL_dtransmat", C.c_void_p), ("dL_dshs_rest", C.c_void_p)]
 
 
+class GsrRowScanJob(C.Structure):
+    """include/gsr.h: the scan of the backward's row counts, offered to kernels between the forward and the backward."""
+    _fields_ = [("counts", C.c_void_p), ("slot_off", C.c_void_p), ("workspace", C.c_void_p), ("n", C.c_int64),
+                ("stage", C.c_int32)]
+
+
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 
 _lock = threading.Lock()
@@ -130,11 +136,18 @@ def lib():
         L.gsr_regularizer_backward.restype = C.c_int32
         L.gsr_regularizer_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float,
                                                C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
-        if hasattr(L, "gsr_loss_backward_finish"):        # (absent from libraries built before it existed: A/B runs)
+        if hasattr(L, "gsr_row_scan_job"):                # (absent from libraries built before it existed: A/B runs)
+            L.gsr_row_scan_job.restype = C.c_int32
+            L.gsr_row_scan_job.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GsrRowScanJob)]
+            L.gsr_backward_with_job.restype = C.c_int32
+            L.gsr_backward_with_job.argtypes = L.gsr_backward.argtypes[:10] + [C.POINTER(GsrRowScanJob)] + \
+                L.gsr_backward.argtypes[10:]
+            L.gsr_loss_forward_job.restype = C.c_int32
+            L.gsr_loss_forward_job.argtypes = L.gsr_loss_forward.argtypes[:-1] + [C.POINTER(GsrRowScanJob), C.c_void_p]
             L.gsr_loss_backward_finish.restype = C.c_int32
             L.gsr_loss_backward_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                    C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
-                                                   C.c_float, C.c_void_p, C.c_void_p]
+                                                   C.c_float, C.c_void_p, C.POINTER(GsrRowScanJob), C.c_void_p]
         L.gsr_objective_finish.restype = C.c_int32
         L.gsr_objective_finish.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
                                            C.c_float, C.c_float, C.c_void_p, C.c_void_p]

@@ -13,90 +13,24 @@
 //
 // All integer work; HBM-bound.  Wave64 throughout: digit matching uses 64-bit ballots.
 #include "gsr_common.h"
+#include "scan_bodies.h"
 #include <type_traits>
 
 // ============================================================================ scan
-#define SCAN_BLOCK 256
-#define SCAN_ITEMS 8
-#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
-
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t n = __shfl_up(v, d, 64);
-        if (lane >= d) v += n;
-    }
-    return v;
-}
-
-// exclusive scan of one value per thread across a 256-thread block; returns block total
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total, uint32_t* wave_tot /*[4+]*/) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t inc = wave_incl_scan(v, lane);
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
-        const uint32_t t = wave_tot[w];
-        if (w < wave) base += t;
-        tot += t;
-    }
-    total = tot;
-    __syncthreads();
-    return base + inc - v;
-}
-
 template <typename T>
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_reduce_kernel(const T* __restrict__ in,
                                                                  const uint32_t* __restrict__ gather,
                                                                  uint32_t* __restrict__ partial, int64_t n) {
     __shared__ uint32_t wt[SCAN_BLOCK / 64];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
-    uint32_t sum = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        const int64_t j = base + (int64_t)i * SCAN_BLOCK + threadIdx.x;
-        if (j < n) sum += gather ? in[gather[j]] : in[j];
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
-    if ((threadIdx.x & 63) == 0) wt[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = wt[0] + wt[1] + wt[2] + wt[3];
+    scan_reduce_body<T>(in, gather, partial, n, (int)blockIdx.x, wt);
 }
-
 template <typename T>
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const T* __restrict__ in,
                                                                 const uint32_t* __restrict__ gather,
                                                                 const uint32_t* __restrict__ partial,
                                                                 uint32_t* __restrict__ out, int64_t n) {
     __shared__ uint32_t wt[SCAN_BLOCK / 64];
-    // thread owns SCAN_ITEMS consecutive elements so the block tile is scanned in index order
-    const int64_t first = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint32_t tsum = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        const int64_t j = first + i;
-        v[i] = j < n ? (gather ? in[gather[j]] : in[j]) : 0;
-        tsum += v[i];
-    }
-    // offset of this tile = sum of the preceding tiles' totals (<= a few thousand values: cheaper than a
-    // third launch that scans them)
-    uint32_t pre = 0;
-    for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_BLOCK) pre += partial[j];
-    uint32_t tile_offset, total;
-    (void)block_excl_scan(pre, tile_offset, wt);
-    uint32_t run = tile_offset + block_excl_scan(tsum, total, wt);
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        const int64_t j = first + i;
-        if (j < n) out[j] = run;
-        run += v[i];
-    }
-    // grand total lands in out[n]
-    if (first <= n - 1 && n - 1 < first + SCAN_ITEMS) out[n] = run;
+    scan_apply_body<T>(in, gather, partial, out, n, (int)blockIdx.x, wt);
 }
 
 size_t gsr_scan_workspace_bytes(int64_t n) {

@@ -373,6 +373,28 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
                                 const int32_t* radii, const void* geom, const void* binning,
                                 const void* image, const float* dL_dcolor, const float* dL_dallmap,
                                 GsrGrads* grads, gsr_alloc_fn alloc, void* ctx, gsr_stream_t stream_) {
+    return gsr_backward_with_job(view, g, num_rendered, radii, geom, binning, image, dL_dcolor, dL_dallmap, grads, nullptr,
+                                 alloc, ctx, stream_);
+}
+
+extern "C" int32_t gsr_row_scan_job(const void* binning, int32_t num_rendered, int32_t width, int32_t height,
+                                    GsrRowScanJob* job) {
+    if (!binning || !job || num_rendered < 0 || width <= 0 || height <= 0) { gsr_set_error("bad row_scan_job arguments"); return GSR_E_INVALID; }
+    const int gx = (width + GSR_TILE - 1) / GSR_TILE, gy = (height + GSR_TILE - 1) / GSR_TILE;
+    const GsrBinLayout BL(num_rendered, gx * gy);
+    job->counts = at<uint8_t>(binning, BL.slot_cnt);
+    job->slot_off = const_cast<uint32_t*>(at<uint32_t>(binning, BL.slot_off));
+    job->workspace = const_cast<char*>(at<char>(binning, BL.row_scan_ws));
+    job->n = num_rendered;
+    job->stage = 0;
+    return GSR_OK;
+}
+
+extern "C" int32_t gsr_backward_with_job(const GsrView* view, const GsrGaussians* g, int32_t num_rendered,
+                                         const int32_t* radii, const void* geom, const void* binning,
+                                         const void* image, const float* dL_dcolor, const float* dL_dallmap,
+                                         GsrGrads* grads, const GsrRowScanJob* job, gsr_alloc_fn alloc, void* ctx,
+                                         gsr_stream_t stream_) {
     int rc = validate(view, g);
     if (rc != GSR_OK) return rc;
     // factored SH gradient: dL_dcolors [N,3] receives the masked colour gradient, the SH arrays are not written
@@ -410,25 +432,28 @@ extern "C" int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int3
     }
     const bool wide = view->channels != 3;
     const size_t row_bytes_each = size_t(GSR_GROW_MAIN + (wide ? 0 : GSR_GROW_XY)) * 4 + (wide ? size_t(view->channels) * 4 : 0);
-    const size_t cnt_bytes = 0;     // (the row-count bytes live in BINNING, cleared by the forward)
-    const size_t slot_bytes = gsr_align((n_inst + 1) * 4);
-    const size_t scan_bytes = gsr_scan_workspace_bytes((int64_t)n_inst);
     const size_t sums_bytes = gsr_align(size_t(N > 0 ? N : 1) * GSR_GROW_FLOATS * 4);
     const size_t begin_bytes = gsr_align(size_t(N + 1) * 4);        // first gradient row of every depth rank
-    char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, cnt_bytes + slot_bytes + scan_bytes + sums_bytes + begin_bytes));
+    char* scratch = static_cast<char*>(alloc(ctx, GSR_BUF_SCRATCH, sums_bytes + begin_bytes));
     if (!scratch) { gsr_set_error("allocator returned NULL (backward scratch)"); return GSR_E_ALLOC; }
+    // (row counts, their scan and its workspace live in BINNING: the forward leaves the counts, and the scan may already
+    // have run as a side job of kernels between the forward and this call)
     uint8_t* slot_cnt = const_cast<uint8_t*>(at<uint8_t>(binning, BL.slot_cnt));
-    uint32_t* slot_off = reinterpret_cast<uint32_t*>(scratch + cnt_bytes);
-    void* scan_ws = scratch + cnt_bytes + slot_bytes;
-    float* row_sums = reinterpret_cast<float*>(scratch + cnt_bytes + slot_bytes + scan_bytes);
-    uint32_t* row_begin = reinterpret_cast<uint32_t*>(scratch + cnt_bytes + slot_bytes + scan_bytes + sums_bytes);
+    uint32_t* slot_off = const_cast<uint32_t*>(at<uint32_t>(binning, BL.slot_off));
+    void* scan_ws = const_cast<char*>(at<char>(binning, BL.row_scan_ws));
+    float* row_sums = reinterpret_cast<float*>(scratch);
+    uint32_t* row_begin = reinterpret_cast<uint32_t*>(scratch + sums_bytes);
+    const bool scanned = job && job->stage == 2 && job->slot_off == slot_off && job->counts == slot_cnt &&
+                         job->n == (int64_t)num_rendered;
 
     size_t n_rows = n_inst * GSR_SUBROWS;       // the bound
     const uint32_t* touch = at<uint32_t>(binning, BL.touch);
     if (num_rendered > 0) {
         // (the row counts per instance were left in BINNING by the forward: render_fwd.hip, last wave of every tile)
-        rc = gsr_exclusive_scan_u8(slot_cnt, slot_off, num_rendered, scan_ws, s);
-        if (rc != GSR_OK) return rc;
+        if (!scanned) {
+            rc = gsr_exclusive_scan_u8(slot_cnt, slot_off, num_rendered, scan_ws, s);
+            if (rc != GSR_OK) return rc;
+        }
         if (n_rows * row_bytes_each > exact_rows_threshold()) {
             uint32_t* r_host = pinned_counter();
             if (!r_host) { gsr_set_error("hipHostMalloc failed (row-count read-back buffer)"); return GSR_E_HIP; }

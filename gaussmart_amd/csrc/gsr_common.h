@@ -85,8 +85,9 @@ struct GsrGeomLayout {
         total = o > 0 ? o : 256;
     }
 };
+size_t gsr_scan_workspace_bytes(int64_t n);
 struct GsrBinLayout {
-    size_t point_list, inst_row, ranges, covered, touch, slot_cnt, total;
+    size_t point_list, inst_row, ranges, covered, touch, slot_cnt, slot_off, row_scan_ws, total;
     // keep_for_backward = false (GSR_FLAG_FORWARD_ONLY): the touch words and the row-count bytes -- the two last regions,
     // 5 B per instance -- are not reserved (the forward-only kernels write neither)
     GsrBinLayout(int64_t D, int64_t tiles, bool keep_for_backward = true) {
@@ -104,6 +105,11 @@ struct GsrBinLayout {
         // gradient rows per instance (emission order), one byte each: cleared by the forward's last binning kernel,
         // filled in by render_fwd (last wave of every tile) for the instances somebody walked
         slot_cnt = o;   o += keep_for_backward ? gsr_align(size_t(D)) : 0;
+        // first gradient row of every instance (exclusive scan of slot_cnt, D + 1 entries) and the scan's workspace: here
+        // rather than in the backward's scratch, so that kernels BETWEEN the forward and the backward can carry the scan
+        // as a side job (GsrRowScanJob)
+        slot_off = o;   o += keep_for_backward ? gsr_align((size_t(D) + 1) * 4) : 0;
+        row_scan_ws = o; o += keep_for_backward ? gsr_scan_workspace_bytes(D > 0 ? D : 1) : 0;
         total = o > 0 ? o : 256;
     }
 };
@@ -118,7 +124,6 @@ struct GsrImageLayout {
 };
 
 // ---------------------------------------------------------------- device primitives (binning.hip)
-size_t gsr_scan_workspace_bytes(int64_t n);
 // exclusive scan of n u32 values; out[n] receives the total (out has n+1 entries).
 // `gather` (may be NULL): in[i] is read as in[gather[i]].
 int gsr_exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,

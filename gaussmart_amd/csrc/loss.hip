@@ -15,6 +15,7 @@
 // HBM-bound streaming: forward reads 8 B and writes 12 B per element, backward reads 20 B and
 // writes 4 B.
 #include "gsr_common.h"
+#include "scan_bodies.h"
 #include <cmath>
 
 #define LS_TILE 16                       // granularity of the partials array (shared with regularizer.hip)
@@ -26,6 +27,19 @@
 #define LS_C2 0.0009f
 
 struct LossWindow { float w[11]; };   // passed by value: lives in the kernarg segment (scalar loads)
+
+// Row-scan side job (include/gsr.h: GsrRowScanJob): workgroups beyond the tiles' carry one half of the exclusive scan of
+// the backward's per-instance row counts -- work no kernel between the forward and the backward depends on.
+struct RowScanArgs { const uint8_t* counts; uint32_t* partial; uint32_t* slot_off; long long n; int blocks; };
+static RowScanArgs make_row_scan(const GsrRowScanJob* job, int want_stage) {
+    RowScanArgs a{nullptr, nullptr, nullptr, 0, 0};
+    if (job && job->stage == want_stage && job->n > 0 && job->counts && job->slot_off && job->workspace) {
+        a.counts = static_cast<const uint8_t*>(job->counts); a.partial = static_cast<uint32_t*>(job->workspace);
+        a.slot_off = static_cast<uint32_t*>(job->slot_off); a.n = job->n;
+        a.blocks = (int)((job->n + SCAN_TILE - 1) / SCAN_TILE);
+    }
+    return a;
+}
 
 static LossWindow make_window() {
     // the reference builds the 1-D window in fp32 (torch.Tensor of python floats, divided by its sum)
@@ -59,12 +73,19 @@ __device__ __forceinline__ void loss_hpass_row4(const float* __restrict__ row, c
 
 __global__ void __launch_bounds__(256, 3) loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
                                                        int C, int H, int W, float* __restrict__ maps,
-                                                       float* __restrict__ partials, LossWindow win) {
+                                                       float* __restrict__ partials, LossWindow win, int tile_wgs,
+                                                       RowScanArgs scan) {
     __shared__ __attribute__((aligned(16))) float sx[LR][LSTR];
     __shared__ __attribute__((aligned(16))) float sy[LR][LSTR];
     __shared__ __attribute__((aligned(16))) float sh[4][LR][LT];
     __shared__ float red[2][4];
     const int t = threadIdx.x;
+    if ((int)blockIdx.x >= tile_wgs) {          // side job: first half of the row scan, one scan tile per workgroup
+        __shared__ uint32_t wt[SCAN_BLOCK / 64];
+        const int sb = (int)blockIdx.x - tile_wgs;
+        if (sb < scan.blocks) scan_reduce_body<uint8_t>(scan.counts, nullptr, scan.partial, scan.n, sb, wt);
+        return;
+    }
     int tile_x, tile_y;
     if (!gsr_xcd_tile((W + LT - 1) / LT, (H + LT - 1) / LT, tile_x, tile_y)) return;
     const int x0 = tile_x * LT, y0 = tile_y * LT;
@@ -242,18 +263,26 @@ __global__ void __launch_bounds__(256) objective_finish_kernel(FinishArgs f) { o
 __global__ void __launch_bounds__(256, 3) loss_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
                                                        const float* __restrict__ maps, int C, int H, int W,
                                                        float lambda, const float* __restrict__ grad_scale,
-                                                       float* __restrict__ dimg, LossWindow win, FinishArgs fin) {
+                                                       float* __restrict__ dimg, LossWindow win, FinishArgs fin, int tile_wgs,
+                                                       RowScanArgs scan) {
     __shared__ __attribute__((aligned(16))) float sm[3][LR][LSTR];
     __shared__ __attribute__((aligned(16))) float sh[3][LR][LT];
     const int t = threadIdx.x;
-    int tile_x, tile_y;
-    if (!gsr_xcd_tile((W + LT - 1) / LT, (H + LT - 1) / LT, tile_x, tile_y)) {
-        // gsr_loss_backward_finish: the launch carries one workgroup without a tile (the last one) that turns the forward's
-        // partials into the five scalars of the objective -- work this kernel does not depend on, so it rides along
-        // instead of being a launch of its own between the forward and the backward kernels
-        if (fin.out != nullptr && blockIdx.x == gridDim.x - 1) objective_finish_body(fin);
+    if ((int)blockIdx.x >= tile_wgs) {
+        // gsr_loss_backward_finish: workgroups beyond the tiles' carry work this kernel does not depend on instead of it
+        // being launches of its own -- the first turns the forward's partials into the five scalars of the objective,
+        // the others run the second half of the row scan of the rasterizer's backward
+        const int sb = (int)blockIdx.x - tile_wgs;
+        if (sb == 0) {
+            if (fin.out != nullptr) objective_finish_body(fin);
+        } else if (sb - 1 < scan.blocks) {
+            __shared__ uint32_t wt[SCAN_BLOCK / 64];
+            scan_apply_body<uint8_t>(scan.counts, nullptr, scan.partial, scan.slot_off, scan.n, sb - 1, wt);
+        }
         return;
     }
+    int tile_x, tile_y;
+    if (!gsr_xcd_tile((W + LT - 1) / LT, (H + LT - 1) / LT, tile_x, tile_y)) return;
     const int x0 = tile_x * LT, y0 = tile_y * LT;
     const size_t HW = (size_t)H * W;
     const float gs = grad_scale[0];
@@ -346,12 +375,20 @@ extern "C" int32_t gsr_loss_num_partials(int32_t H, int32_t W) {
 
 extern "C" int32_t gsr_loss_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W,
                                     float* maps, float* partials, gsr_stream_t stream_) {
+    return gsr_loss_forward_job(img, gt, C, H, W, maps, partials, nullptr, stream_);
+}
+
+extern "C" int32_t gsr_loss_forward_job(const float* img, const float* gt, int32_t C, int32_t H, int32_t W,
+                                        float* maps, float* partials, GsrRowScanJob* job, gsr_stream_t stream_) {
     if (!img || !gt || !maps || !partials || C <= 0 || H <= 0 || W <= 0) { gsr_set_error("bad loss_forward arguments"); return GSR_E_INVALID; }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GsrProfileScope prof(GSR_K_LOSS_FWD, s);
-    dim3 grid(gsr_xcd_tile_grid(((W + LT - 1) / LT) * ((H + LT - 1) / LT)));
-    hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(256), 0, s, img, gt, C, H, W, maps, partials, make_window());
+    const unsigned tile_wgs = gsr_xcd_tile_grid(((W + LT - 1) / LT) * ((H + LT - 1) / LT));
+    const RowScanArgs scan = make_row_scan(job, 0);
+    hipLaunchKernelGGL(loss_fwd_kernel, dim3(tile_wgs + (unsigned)scan.blocks), dim3(256), 0, s, img, gt, C, H, W, maps, partials,
+                       make_window(), (int)tile_wgs, scan);
     GSR_LAUNCH_CHECK();
+    if (scan.blocks > 0) job->stage = 1;
     return GSR_OK;
 }
 
@@ -361,10 +398,10 @@ extern "C" int32_t gsr_loss_backward(const float* img, const float* gt, const fl
     if (!img || !gt || !maps || !grad_scale || !dimg || C <= 0 || H <= 0 || W <= 0) { gsr_set_error("bad loss_backward arguments"); return GSR_E_INVALID; }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GsrProfileScope prof(GSR_K_LOSS_BWD, s);
-    dim3 grid(gsr_xcd_tile_grid(((W + LT - 1) / LT) * ((H + LT - 1) / LT)));
+    const unsigned tile_wgs = gsr_xcd_tile_grid(((W + LT - 1) / LT) * ((H + LT - 1) / LT));
     FinishArgs none{};
-    hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, s, img, gt, maps, C, H, W, lambda_dssim, grad_scale, dimg, make_window(),
-                       none);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(tile_wgs), dim3(256), 0, s, img, gt, maps, C, H, W, lambda_dssim, grad_scale, dimg,
+                       make_window(), none, (int)tile_wgs, make_row_scan(nullptr, 0));
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }
@@ -383,18 +420,22 @@ static FinishArgs make_finish(const float* loss_partials, int C, int H, int W, c
 extern "C" int32_t gsr_loss_backward_finish(const float* img, const float* gt, const float* maps, int32_t C, int32_t H,
                                             int32_t W, float lambda_dssim, const float* grad_scale, float* dimg,
                                             const float* loss_partials, const float* reg_partials, float lambda_normal,
-                                            float lambda_dist, float* out5, gsr_stream_t stream_) {
-    if (!img || !gt || !maps || !grad_scale || !dimg || !loss_partials || !out5 || C <= 0 || H <= 0 || W <= 0) {
+                                            float lambda_dist, float* out5, GsrRowScanJob* job, gsr_stream_t stream_) {
+    if (!img || !gt || !maps || !grad_scale || !dimg || (out5 && !loss_partials) || C <= 0 || H <= 0 || W <= 0) {
         gsr_set_error("bad loss_backward_finish arguments");
         return GSR_E_INVALID;
     }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GsrProfileScope prof(GSR_K_LOSS_BWD, s);
-    // one more row of eight workgroups than the tiles need: the last of them has no tile by construction
-    dim3 grid(gsr_xcd_tile_grid(((W + LT - 1) / LT) * ((H + LT - 1) / LT)) + 8u);
-    hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, s, img, gt, maps, C, H, W, lambda_dssim, grad_scale, dimg, make_window(),
-                       make_finish(loss_partials, C, H, W, reg_partials, lambda_dssim, lambda_normal, lambda_dist, out5));
+    const unsigned tile_wgs = gsr_xcd_tile_grid(((W + LT - 1) / LT) * ((H + LT - 1) / LT));
+    const RowScanArgs scan = make_row_scan(job, 1);
+    FinishArgs fin{};
+    if (out5) fin = make_finish(loss_partials, C, H, W, reg_partials, lambda_dssim, lambda_normal, lambda_dist, out5);
+    const unsigned extra = (out5 || scan.blocks > 0) ? 1u + (unsigned)scan.blocks : 0u;   // [finish][scan tiles...]
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(tile_wgs + extra), dim3(256), 0, s, img, gt, maps, C, H, W, lambda_dssim, grad_scale,
+                       dimg, make_window(), fin, (int)tile_wgs, scan);
     GSR_LAUNCH_CHECK();
+    if (scan.blocks > 0) job->stage = 2;
     return GSR_OK;
 }
 

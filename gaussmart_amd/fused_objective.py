@@ -35,8 +35,17 @@ class _Objective(torch.autograd.Function):
             partials = torch.empty((2, n_part), dtype=torch.float32, device=dev)
             out = torch.empty(5, dtype=torch.float32, device=dev)
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(L.gsr_loss_forward(C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()), Cn, H, W,
-                                          C.c_void_p(maps.data_ptr()), C.c_void_p(partials[0].data_ptr()), stream))
+            # the scan the rasterizer's backward starts with rides along with these launches, if its forward offered it
+            from . import rasterizer as _rast
+            job = _rast.take_row_scan_job(dev) if (ctx.needs_input_grad[0] and hasattr(L, "gsr_loss_forward_job")) else None
+            ctx.row_scan_job = job
+            if job is not None:
+                _lib.check(L.gsr_loss_forward_job(C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()), Cn, H, W,
+                                                  C.c_void_p(maps.data_ptr()), C.c_void_p(partials[0].data_ptr()),
+                                                  C.byref(job), stream))
+            else:
+                _lib.check(L.gsr_loss_forward(C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()), Cn, H, W,
+                                              C.c_void_p(maps.data_ptr()), C.c_void_p(partials[0].data_ptr()), stream))
             reg_ptr = None
             if use_reg:
                 _lib.check(L.gsr_regularizer_forward(C.c_void_p(am.data_ptr()), H, W, kinv, float(depth_ratio),
@@ -45,7 +54,7 @@ class _Objective(torch.autograd.Function):
             # defer_value (training_step: the backward follows at once and nobody reads the value in between): the five
             # scalars are computed by a workgroup riding along with the backward's first kernel (gsr_loss_backward_finish)
             ctx.deferred = None
-            if defer_value and ctx.needs_input_grad[0] and hasattr(L, "gsr_loss_backward_finish"):
+            if defer_value and ctx.needs_input_grad[0] and hasattr(L, "gsr_loss_forward_job"):
                 ctx.deferred = (partials, out, use_reg)
             else:
                 _lib.check(L.gsr_objective_finish(C.c_void_p(partials[0].data_ptr()), Cn, H, W, reg_ptr,
@@ -78,13 +87,18 @@ class _Objective(torch.autograd.Function):
             scale = g_total.detach().float().reshape(1).contiguous()
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             dimg = torch.empty_like(img)
-            if ctx.deferred is not None:
-                partials, out, with_reg = ctx.deferred
+            job = getattr(ctx, "row_scan_job", None)
+            ctx.row_scan_job = None
+            if ctx.deferred is not None or job is not None:
+                partials, out, with_reg = ctx.deferred if ctx.deferred is not None else (None, None, False)
                 ctx.deferred = None
                 _lib.check(L.gsr_loss_backward_finish(
                     C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()), C.c_void_p(maps.data_ptr()), Cn, H, W, ld,
-                    C.c_void_p(scale.data_ptr()), C.c_void_p(dimg.data_ptr()), C.c_void_p(partials[0].data_ptr()),
-                    C.c_void_p(partials[1].data_ptr()) if with_reg else None, ln, ldist, C.c_void_p(out.data_ptr()), stream))
+                    C.c_void_p(scale.data_ptr()), C.c_void_p(dimg.data_ptr()),
+                    C.c_void_p(partials[0].data_ptr()) if partials is not None else None,
+                    C.c_void_p(partials[1].data_ptr()) if with_reg else None, ln, ldist,
+                    C.c_void_p(out.data_ptr()) if out is not None else None,
+                    C.byref(job) if job is not None else None, stream))
             else:
                 _lib.check(L.gsr_loss_backward(C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()),
                                                C.c_void_p(maps.data_ptr()), Cn, H, W, ld, C.c_void_p(scale.data_ptr()),

@@ -116,7 +116,8 @@ class _BufferPool:
 
 
 _POOL = _BufferPool()
-STATS = {"color_pass_on_second_stream": 0}     # how often a forward put its SH colour pass on the updater's stream
+STATS = {"color_pass_on_second_stream": 0,     # how often a forward put its SH colour pass on the updater's stream
+         "row_scans_carried": 0}               # how often a backward found its row scan done by the objective's kernels
 _POOL_DEBUG = bool(__import__("os").environ.get("GSR_POOL_DEBUG"))
 
 
@@ -221,6 +222,18 @@ def set_pending_param_event(device, event, stream=None, model=None):
     its xyz parameter) then puts its SH colour pass on that stream too (GSR_BUF_COLOR_STREAM), behind the update, while
     its own stream sorts and bins.  Forwards of other models on the same device are not affected."""
     _PENDING_PARAM_EVENT[(torch.device(device), _model_key(model))] = (event, stream)
+
+
+# Row-scan side job (include/gsr.h: GsrRowScanJob): the raw forward describes the scan its backward starts with and parks
+# the description here; the fused objective, whose kernels run between the two, picks it up and carries the scan in
+# extra workgroups of its own launches.  The job holds the forward's buffer lease, so the buffers outlive the kernels
+# that write into them whatever happens to the autograd graph.  GSR_ROW_SCAN_RIDE=0 switches the hand-over off.
+_ROW_SCAN_JOB = {}            # device -> job of the latest raw forward that kept its buffers for a backward
+_ROW_SCAN_RIDE = __import__("os").environ.get("GSR_ROW_SCAN_RIDE", "1") != "0"
+
+
+def take_row_scan_job(device):
+    return _ROW_SCAN_JOB.pop(torch.device(device), None)
 
 
 def _pop_pending(device, model):
@@ -483,6 +496,14 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         ctx.raster_settings, ctx.flags, ctx.num_rendered, ctx.M = rs, flags & ~_lib.GSR_FLAG_DEFER_COLOR, int(out.num_rendered), M
         ctx.view_keep = keep
         ctx.color_cache = color_cache        # (the backward reads d(rgb)/d(dir) from it)
+        ctx.row_scan_job = None
+        if _ROW_SCAN_RIDE and hasattr(L, "gsr_row_scan_job") and int(out.num_rendered) > 0:
+            job = _lib.GsrRowScanJob()
+            _lib.check(L.gsr_row_scan_job(C.c_void_p(alloc.buffers[_lib.GSR_BUF_BINNING].data_ptr()), int(out.num_rendered),
+                                          W, H, C.byref(job)))
+            job._lease = alloc.kept            # keeps BINNING out of the pool while anybody may still write into it
+            ctx.row_scan_job = job
+            _ROW_SCAN_JOB[torch.device(device)] = job
         ctx.set_materialize_grads(False)     # no zero tensors for the unused radii / image gradients
         ctx.save_for_backward(xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, radii,
                               alloc.buffers[_lib.GSR_BUF_GEOM], alloc.buffers[_lib.GSR_BUF_BINNING],
@@ -533,9 +554,19 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                                       _ptr(d_rest) if rest is not None else None)
             alloc = _Allocator(device)
             stream = torch.cuda.current_stream(device).cuda_stream
-            rc = L.gsr_backward(C.byref(view), C.byref(g), ctx.num_rendered, _ptr(radii), _ptr(geom), _ptr(binning),
-                                _ptr(image), _ptr(grad_color), _ptr(grad_allmap), C.byref(grads), alloc.cb, None,
-                                C.c_void_p(stream))
+            job = getattr(ctx, "row_scan_job", None)
+            if _ROW_SCAN_JOB.get(torch.device(device)) is job:
+                _ROW_SCAN_JOB.pop(torch.device(device), None)        # nobody picked it up: the backward scans itself
+            if job is not None:
+                rc = L.gsr_backward_with_job(C.byref(view), C.byref(g), ctx.num_rendered, _ptr(radii), _ptr(geom),
+                                             _ptr(binning), _ptr(image), _ptr(grad_color), _ptr(grad_allmap), C.byref(grads),
+                                             C.byref(job), alloc.cb, None, C.c_void_p(stream))
+                STATS["row_scans_carried"] += int(job.stage == 2)
+                job._lease = None
+            else:
+                rc = L.gsr_backward(C.byref(view), C.byref(g), ctx.num_rendered, _ptr(radii), _ptr(geom), _ptr(binning),
+                                    _ptr(image), _ptr(grad_color), _ptr(grad_allmap), C.byref(grads), alloc.cb, None,
+                                    C.c_void_p(stream))
             alloc.done()
             if rc != 0 and alloc.error is not None:
                 raise alloc.error

@@ -185,6 +185,26 @@ int32_t gsr_backward(const GsrView* view, const GsrGaussians* g, int32_t num_ren
                      const void* image, const float* dL_dcolor, const float* dL_dallmap,
                      GsrGrads* grads, gsr_alloc_fn alloc, void* alloc_ctx, gsr_stream_t stream);
 
+/* The backward starts with an exclusive scan of the per-instance gradient-row counts the forward left in BINNING (two
+ * small launches).  Nothing between the forward and the backward depends on it, so kernels that run in between can carry it
+ * as a side job: gsr_row_scan_job describes it (pointers into BINNING), gsr_loss_forward_job / gsr_loss_backward_finish
+ * take the description and run its two halves in extra workgroups of their own launches (recording that in `stage`), and
+ * gsr_backward_with_job skips the scan when it finds both halves done for exactly its buffers.  Entirely optional: with
+ * stage < 2 (or no job) the backward scans itself. */
+typedef struct GsrRowScanJob {
+    const void* counts;      /* device u8[n]   (BINNING "row_count") */
+    void* slot_off;          /* device u32[n + 1] */
+    void* workspace;         /* device, scan partials */
+    int64_t n;               /* instances (num_rendered) */
+    int32_t stage;           /* host-side: 0 = nothing enqueued, 1 = first half enqueued, 2 = both */
+} GsrRowScanJob;
+int32_t gsr_row_scan_job(const void* binning, int32_t num_rendered, int32_t width, int32_t height, GsrRowScanJob* job);
+int32_t gsr_backward_with_job(const GsrView* view, const GsrGaussians* g, int32_t num_rendered,
+                              const int32_t* radii, const void* geom, const void* binning,
+                              const void* image, const float* dL_dcolor, const float* dL_dallmap,
+                              GsrGrads* grads, const GsrRowScanJob* job, gsr_alloc_fn alloc, void* alloc_ctx,
+                              gsr_stream_t stream);
+
 /* Introspection of the saved buffers, for parity tests.  Writes byte offset and size of a named
  * field inside buffer `which` for a problem of N Gaussians, D instances, W x H pixels.
  * Names: GEOM: "splat" f32[N,20], "clamped" u32[N], "tiles_touched" u32[N], "depth_key" u32[N],
@@ -249,11 +269,16 @@ int32_t gsr_objective_finish(const float* loss_partials, int32_t C, int32_t H, i
 /* gsr_loss_backward and gsr_objective_finish as ONE launch: the backward kernel does not depend on the five scalars, so the
  * workgroup that computes them rides along with it (one kernel boundary less between the forward and the backward of the
  * objective).  For callers that run the backward right after the forward and read the loss value only afterwards: out5 is
- * written by THIS call, not by the forward.  Same values as the two separate calls. */
+ * written by THIS call, not by the forward.  Same values as the two separate calls.  (GsrRowScanJob: see gsr_row_scan_job.) */
 int32_t gsr_loss_backward_finish(const float* img, const float* gt, const float* maps, int32_t C, int32_t H,
                                  int32_t W, float lambda_dssim, const float* grad_scale, float* dimg,
                                  const float* loss_partials, const float* reg_partials, float lambda_normal,
-                                 float lambda_dist, float* out5, gsr_stream_t stream);
+                                 float lambda_dist, float* out5 /* NULL: no scalars */,
+                                 GsrRowScanJob* job /* NULL, or a job at stage 1: its second half rides along */,
+                                 gsr_stream_t stream);
+/* gsr_loss_forward with the first half of a row-scan job (stage 0 -> 1) in extra workgroups of its launch. */
+int32_t gsr_loss_forward_job(const float* img, const float* gt, int32_t C, int32_t H, int32_t W,
+                             float* maps, float* partials, GsrRowScanJob* job, gsr_stream_t stream);
 
 /* Dense Adam step over up to 8 parameter tensors in one launch; the update of
  * torch.optim.Adam as the reference configures it (scene/gaussian_model.py:282-295).  All arrays

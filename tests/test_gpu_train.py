@@ -169,3 +169,39 @@ def test_train_cli_on_blender_style_scene(gpu_device, tmp_path):
     res = json.load(open(out / "results.json"))
     assert res["iterations"] == 700 and res["points"] > 0 and res["psnr_train"] > 15.0 and res["psnr_test"] > 12.0
     assert os.path.exists(out / "point_cloud" / "iteration_700" / "point_cloud.ply") and os.path.exists(out / "chkpnt700.pth")
+
+
+def test_row_scan_carried_by_the_objective_kernels(gpu_device, monkeypatch):
+    """GsrRowScanJob (include/gsr.h): the exclusive scan the rasterizer's backward starts with runs in extra workgroups of
+    the objective's launches.  Same gradients, bit for bit, as with the hand-over switched off; the counter shows the
+    backward really found the scan done."""
+    from gaussmart_amd import rasterizer as R
+    from gaussmart_amd.gaussian_model import GaussianModel
+    from gaussmart_amd.gaussian_renderer import render
+    from gaussmart_amd.params import OptimizationParams, PipelineParams
+    from gaussmart_amd.synthetic import make_scene, perturb, jittered_cameras
+    from gaussmart_amd.trainer import training_losses
+    dev = gpu_device
+    params, _ = make_scene(30000, 400, 240, seed=11)
+    cam = jittered_cameras(2, 400, 240, seed=11, device=dev, amount=0.3)[1]
+    pipe, opt, bg = PipelineParams(), OptimizationParams(), torch.zeros(3, device=dev)
+    tgt = GaussianModel(3, device=dev)
+    tgt.create_from_params(perturb(params))
+    with torch.no_grad():
+        gt = render(cam, tgt, pipe, bg)["render"].clamp(0, 1).contiguous()
+    grads = []
+    for ride in (False, True):
+        monkeypatch.setattr(R, "_ROW_SCAN_RIDE", ride)
+        m = GaussianModel(3, device=dev)
+        m.create_from_params(params)
+        m.training_setup(opt)
+        before = R.STATS["row_scans_carried"]
+        pkg = render(cam, m, pipe, bg, surface_maps=False)
+        total, _ = training_losses(pkg, gt, opt, 10000, cam, pipe)
+        total.backward()
+        torch.cuda.synchronize()
+        assert R.STATS["row_scans_carried"] - before == int(ride)
+        grads.append([p.grad.clone() for p in m.parameters() if p.grad is not None] + [total.detach().clone()])
+    assert len(grads[0]) == len(grads[1]) > 4
+    for a, b in zip(grads[0], grads[1]):
+        assert torch.equal(a, b)
