@@ -136,6 +136,9 @@ def lib():
         L.gsr_regularizer_backward.restype = C.c_int32
         L.gsr_regularizer_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float,
                                                C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        if hasattr(L, "gsr_regularizer_backward_partials"):   # (absent from libraries built before it existed: A/B runs)
+            L.gsr_regularizer_backward_partials.restype = C.c_int32
+            L.gsr_regularizer_backward_partials.argtypes = L.gsr_regularizer_backward.argtypes[:-1] + [C.c_void_p, C.c_void_p]
         if hasattr(L, "gsr_row_scan_job"):                # (absent from libraries built before it existed: A/B runs)
             L.gsr_row_scan_job.restype = C.c_int32
             L.gsr_row_scan_job.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GsrRowScanJob)]

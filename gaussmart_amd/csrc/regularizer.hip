@@ -121,12 +121,15 @@ __global__ void __launch_bounds__(256) reg_fwd_kernel(RegParams p, const float* 
 __global__ void __launch_bounds__(256) reg_bwd_kernel(RegParams p, const float* __restrict__ am,
                                                       float lambda_normal, float lambda_dist,
                                                       const float* __restrict__ grad_scale,
-                                                      float* __restrict__ dam) {
+                                                      float* __restrict__ dam, float* __restrict__ partials) {
     __shared__ float sd[RG_T + 4][RG_T + 5];          // surf_depth, halo 2
     __shared__ float sg[6][RG_T + 2][RG_T + 3];       // dL/ddx, dL/ddy of every pixel, halo 1
+    __shared__ float sn_in[3][RG_T + 2][RG_T + 3];    // rendered normal of every pixel, halo 1 (only read with `partials`)
+    __shared__ float red[2][4];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int tiles_x = (p.W + RG_T - 1) / RG_T;
     int tile_x, tile_y;
-    if (!gsr_xcd_tile((p.W + RG_T - 1) / RG_T, (p.H + RG_T - 1) / RG_T, tile_x, tile_y)) return;
+    if (!gsr_xcd_tile(tiles_x, (p.H + RG_T - 1) / RG_T, tile_x, tile_y)) return;
     const int x0 = tile_x * RG_T, y0 = tile_y * RG_T;
     const size_t HW = (size_t)p.W * p.H;
     const float inv_n = 1.0f / ((float)p.W * (float)p.H);
@@ -187,9 +190,39 @@ __global__ void __launch_bounds__(256) reg_bwd_kernel(RegParams p, const float* 
         }
         sg[0][r][q] = gdx.x; sg[1][r][q] = gdx.y; sg[2][r][q] = gdx.z;
         sg[3][r][q] = gdy.x; sg[4][r][q] = gdy.y; sg[5][r][q] = gdy.z;
+        if (partials) { sn_in[0][r][q] = p1_n0[u]; sn_in[1][r][q] = p1_n1[u]; sn_in[2][r][q] = p1_n2[u]; }
     }
     __syncthreads();
     const int x = fx, y = fy;
+    // `partials` (gsr_regularizer_backward_partials): this launch also leaves what reg_fwd would have -- the tile's sums of
+    // the normal error and of the distortion -- so a training step that runs the backward anyway needs no forward launch
+    // of the regularizer.  Same per-pixel expression, same reduction tree, same slot as reg_fwd_kernel.
+    float err = 0.f, dist = 0.f;
+    if (partials && f_in) {
+        float dotp = 0.f;
+        if (x >= 1 && x <= p.W - 2 && y >= 1 && y <= p.H - 2) {
+            const float3 ru = rg_ray(p, x, y + 1), rd = rg_ray(p, x, y - 1), rr = rg_ray(p, x + 1, y), rl = rg_ray(p, x - 1, y);
+            const float du = sd[ty + 3][tx + 2], dd = sd[ty + 1][tx + 2], dr = sd[ty + 2][tx + 3], dl = sd[ty + 2][tx + 1];
+            const float3 dx = make_float3(du * ru.x - dd * rd.x, du * ru.y - dd * rd.y, du * ru.z - dd * rd.z);
+            const float3 dy = make_float3(dr * rr.x - dl * rl.x, dr * rr.y - dl * rl.y, dr * rr.z - dl * rl.z);
+            const float3 c = rg_cross(dx, dy);
+            const float inv = 1.0f / fmaxf(sqrtf(c.x * c.x + c.y * c.y + c.z * c.z), 1e-12f);
+            dotp = (sn_in[0][ty + 1][tx + 1] * c.x + sn_in[1][ty + 1][tx + 1] * c.y + sn_in[2][ty + 1][tx + 1] * c.z) * inv * fA;
+        }
+        err = 1.0f - dotp;
+        dist = am[6 * HW + fo];
+    }
+    if (partials) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { err += __shfl_down(err, d, 64); dist += __shfl_down(dist, d, 64); }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = err; red[1][threadIdx.x >> 6] = dist; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int b = tile_y * tiles_x + tile_x;
+            partials[2 * b + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            partials[2 * b + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        }
+    }
     if (!f_in) return;
     const size_t o = fo;
     const int r = ty + 1, q = tx + 1;     // position inside the halo-1 arrays
@@ -250,6 +283,14 @@ extern "C" int32_t gsr_regularizer_forward(const float* allmap, int32_t H, int32
 extern "C" int32_t gsr_regularizer_backward(const float* allmap, int32_t H, int32_t W, const float* kinv_host,
                                             float depth_ratio, float lambda_normal, float lambda_dist,
                                             const float* grad_scale, float* d_allmap, gsr_stream_t stream_) {
+    return gsr_regularizer_backward_partials(allmap, H, W, kinv_host, depth_ratio, lambda_normal, lambda_dist, grad_scale,
+                                             d_allmap, nullptr, stream_);
+}
+
+extern "C" int32_t gsr_regularizer_backward_partials(const float* allmap, int32_t H, int32_t W, const float* kinv_host,
+                                                     float depth_ratio, float lambda_normal, float lambda_dist,
+                                                     const float* grad_scale, float* d_allmap, float* partials,
+                                                     gsr_stream_t stream_) {
     RegParams p;
     int rc = fill_params(p, H, W, depth_ratio, kinv_host);
     if (rc != GSR_OK) return rc;
@@ -257,7 +298,8 @@ extern "C" int32_t gsr_regularizer_backward(const float* allmap, int32_t H, int3
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GsrProfileScope prof(GSR_K_REG_BWD, s);
     dim3 grid(gsr_xcd_tile_grid(((W + RG_T - 1) / RG_T) * ((H + RG_T - 1) / RG_T)));
-    hipLaunchKernelGGL(reg_bwd_kernel, grid, dim3(256), 0, s, p, allmap, lambda_normal, lambda_dist, grad_scale, d_allmap);
+    hipLaunchKernelGGL(reg_bwd_kernel, grid, dim3(256), 0, s, p, allmap, lambda_normal, lambda_dist, grad_scale, d_allmap,
+                       partials);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

@@ -46,15 +46,20 @@ class _Objective(torch.autograd.Function):
             else:
                 _lib.check(L.gsr_loss_forward(C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()), Cn, H, W,
                                               C.c_void_p(maps.data_ptr()), C.c_void_p(partials[0].data_ptr()), stream))
+            # defer_value (training_step: the backward follows at once and nobody reads the value in between): the five
+            # scalars are computed by a workgroup riding along with a kernel of the backward (gsr_loss_backward_finish), and
+            # the regularizer's forward sums -- which only feed those scalars -- come from its backward kernel, which
+            # evaluates every pixel's surface normal anyway (gsr_regularizer_backward_partials): no forward launch of it
+            defer = bool(defer_value and ctx.needs_input_grad[0] and hasattr(L, "gsr_loss_forward_job")
+                         and (not use_reg or (ctx.needs_input_grad[1] and hasattr(L, "gsr_regularizer_backward_partials"))))
             reg_ptr = None
-            if use_reg:
+            if use_reg and not defer:
                 _lib.check(L.gsr_regularizer_forward(C.c_void_p(am.data_ptr()), H, W, kinv, float(depth_ratio),
                                                      C.c_void_p(partials[1].data_ptr()), stream))
+            if use_reg:
                 reg_ptr = C.c_void_p(partials[1].data_ptr())
-            # defer_value (training_step: the backward follows at once and nobody reads the value in between): the five
-            # scalars are computed by a workgroup riding along with the backward's first kernel (gsr_loss_backward_finish)
             ctx.deferred = None
-            if defer_value and ctx.needs_input_grad[0] and hasattr(L, "gsr_loss_forward_job"):
+            if defer:
                 ctx.deferred = (partials, out, use_reg)
             else:
                 _lib.check(L.gsr_objective_finish(C.c_void_p(partials[0].data_ptr()), Cn, H, W, reg_ptr,
@@ -89,9 +94,19 @@ class _Objective(torch.autograd.Function):
             dimg = torch.empty_like(img)
             job = getattr(ctx, "row_scan_job", None)
             ctx.row_scan_job = None
-            if ctx.deferred is not None or job is not None:
-                partials, out, with_reg = ctx.deferred if ctx.deferred is not None else (None, None, False)
-                ctx.deferred = None
+            deferred, ctx.deferred = ctx.deferred, None
+            if ctx.use_reg:       # first: with a deferred value its launch also leaves the regularizer's forward sums
+                am = saved[3]
+                dam = torch.empty_like(am)
+                if deferred is not None:
+                    _lib.check(L.gsr_regularizer_backward_partials(
+                        C.c_void_p(am.data_ptr()), H, W, kinv, ratio, ln, ldist, C.c_void_p(scale.data_ptr()),
+                        C.c_void_p(dam.data_ptr()), C.c_void_p(deferred[0][1].data_ptr()), stream))
+                else:
+                    _lib.check(L.gsr_regularizer_backward(C.c_void_p(am.data_ptr()), H, W, kinv, ratio, ln, ldist,
+                                                          C.c_void_p(scale.data_ptr()), C.c_void_p(dam.data_ptr()), stream))
+            if deferred is not None or job is not None:
+                partials, out, with_reg = deferred if deferred is not None else (None, None, False)
                 _lib.check(L.gsr_loss_backward_finish(
                     C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()), C.c_void_p(maps.data_ptr()), Cn, H, W, ld,
                     C.c_void_p(scale.data_ptr()), C.c_void_p(dimg.data_ptr()),
@@ -103,11 +118,6 @@ class _Objective(torch.autograd.Function):
                 _lib.check(L.gsr_loss_backward(C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()),
                                                C.c_void_p(maps.data_ptr()), Cn, H, W, ld, C.c_void_p(scale.data_ptr()),
                                                C.c_void_p(dimg.data_ptr()), stream))
-            if ctx.use_reg:
-                am = saved[3]
-                dam = torch.empty_like(am)
-                _lib.check(L.gsr_regularizer_backward(C.c_void_p(am.data_ptr()), H, W, kinv, ratio, ln, ldist,
-                                                      C.c_void_p(scale.data_ptr()), C.c_void_p(dam.data_ptr()), stream))
         return dimg, dam, None, None, None, None, None, None, None
 
 

@@ -257,6 +257,13 @@ int32_t gsr_regularizer_forward(const float* allmap, int32_t H, int32_t W, const
 int32_t gsr_regularizer_backward(const float* allmap, int32_t H, int32_t W, const float* kinv_host,
                                  float depth_ratio, float lambda_normal, float lambda_dist,
                                  const float* grad_scale, float* d_allmap, gsr_stream_t stream);
+/* gsr_regularizer_backward that ALSO leaves the partials gsr_regularizer_forward would have written (partials != NULL): the
+ * backward evaluates every pixel's surface normal anyway, so a caller that runs the backward right after the forward and
+ * reads the loss value only afterwards needs no forward launch of the regularizer at all. */
+int32_t gsr_regularizer_backward_partials(const float* allmap, int32_t H, int32_t W, const float* kinv_host,
+                                          float depth_ratio, float lambda_normal, float lambda_dist,
+                                          const float* grad_scale, float* d_allmap, float* partials,
+                                          gsr_stream_t stream);
 
 /* The whole training objective from the partials of gsr_loss_forward (and, when reg_partials is
  * non-NULL, gsr_regularizer_forward) in one tiny launch:
