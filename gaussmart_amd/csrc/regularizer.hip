@@ -197,18 +197,24 @@ __global__ void __launch_bounds__(256) reg_bwd_kernel(RegParams p, const float* 
     // `partials` (gsr_regularizer_backward_partials): this launch also leaves what reg_fwd would have -- the tile's sums of
     // the normal error and of the distortion -- so a training step that runs the backward anyway needs no forward launch
     // of the regularizer.  Same per-pixel expression, same reduction tree, same slot as reg_fwd_kernel.
+    // the pixel's own finite differences: needed below for d/d(rendered normal) and, with `partials`, for the forward value
+    const bool interior = f_in && x >= 1 && x <= p.W - 2 && y >= 1 && y <= p.H - 2;
+    float3 c_px = make_float3(0.f, 0.f, 0.f);
+    float inv_px = 0.f;
+    if (interior) {
+        const float3 ru = rg_ray(p, x, y + 1), rd = rg_ray(p, x, y - 1), rr = rg_ray(p, x + 1, y), rl = rg_ray(p, x - 1, y);
+        const float du = sd[ty + 3][tx + 2], dd = sd[ty + 1][tx + 2], dr = sd[ty + 2][tx + 3], dl = sd[ty + 2][tx + 1];
+        const float3 dx = make_float3(du * ru.x - dd * rd.x, du * ru.y - dd * rd.y, du * ru.z - dd * rd.z);
+        const float3 dy = make_float3(dr * rr.x - dl * rl.x, dr * rr.y - dl * rl.y, dr * rr.z - dl * rl.z);
+        c_px = rg_cross(dx, dy);
+        inv_px = 1.0f / fmaxf(sqrtf(c_px.x * c_px.x + c_px.y * c_px.y + c_px.z * c_px.z), 1e-12f);
+    }
     float err = 0.f, dist = 0.f;
     if (partials && f_in) {
         float dotp = 0.f;
-        if (x >= 1 && x <= p.W - 2 && y >= 1 && y <= p.H - 2) {
-            const float3 ru = rg_ray(p, x, y + 1), rd = rg_ray(p, x, y - 1), rr = rg_ray(p, x + 1, y), rl = rg_ray(p, x - 1, y);
-            const float du = sd[ty + 3][tx + 2], dd = sd[ty + 1][tx + 2], dr = sd[ty + 2][tx + 3], dl = sd[ty + 2][tx + 1];
-            const float3 dx = make_float3(du * ru.x - dd * rd.x, du * ru.y - dd * rd.y, du * ru.z - dd * rd.z);
-            const float3 dy = make_float3(dr * rr.x - dl * rl.x, dr * rr.y - dl * rl.y, dr * rr.z - dl * rl.z);
-            const float3 c = rg_cross(dx, dy);
-            const float inv = 1.0f / fmaxf(sqrtf(c.x * c.x + c.y * c.y + c.z * c.z), 1e-12f);
-            dotp = (sn_in[0][ty + 1][tx + 1] * c.x + sn_in[1][ty + 1][tx + 1] * c.y + sn_in[2][ty + 1][tx + 1] * c.z) * inv * fA;
-        }
+        if (interior)
+            dotp = (sn_in[0][ty + 1][tx + 1] * c_px.x + sn_in[1][ty + 1][tx + 1] * c_px.y + sn_in[2][ty + 1][tx + 1] * c_px.z) *
+                   inv_px * fA;
         err = 1.0f - dotp;
         dist = am[6 * HW + fo];
     }
@@ -245,15 +251,7 @@ __global__ void __launch_bounds__(256) reg_bwd_kernel(RegParams p, const float* 
     dam[6 * HW + o] = kd;
     // rendered normal: error = 1 - N . (s * alpha)
     float3 sn = make_float3(0.f, 0.f, 0.f);
-    if (x >= 1 && x <= p.W - 2 && y >= 1 && y <= p.H - 2) {
-        const float3 ru = rg_ray(p, x, y + 1), rd = rg_ray(p, x, y - 1), rr = rg_ray(p, x + 1, y), rl = rg_ray(p, x - 1, y);
-        const float du = sd[ty + 3][tx + 2], dd = sd[ty + 1][tx + 2], dr = sd[ty + 2][tx + 3], dl = sd[ty + 2][tx + 1];
-        const float3 dx = make_float3(du * ru.x - dd * rd.x, du * ru.y - dd * rd.y, du * ru.z - dd * rd.z);
-        const float3 dy = make_float3(dr * rr.x - dl * rl.x, dr * rr.y - dl * rl.y, dr * rr.z - dl * rl.z);
-        const float3 c = rg_cross(dx, dy);
-        const float inv = 1.0f / fmaxf(sqrtf(c.x * c.x + c.y * c.y + c.z * c.z), 1e-12f);
-        sn = make_float3(c.x * inv * A, c.y * inv * A, c.z * inv * A);
-    }
+    if (interior) sn = make_float3(c_px.x * inv_px * A, c_px.y * inv_px * A, c_px.z * inv_px * A);
     dam[2 * HW + o] = -kn * sn.x;
     dam[3 * HW + o] = -kn * sn.y;
     dam[4 * HW + o] = -kn * sn.z;
