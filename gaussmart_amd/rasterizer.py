@@ -233,7 +233,12 @@ _ROW_SCAN_RIDE = __import__("os").environ.get("GSR_ROW_SCAN_RIDE", "1") != "0"
 
 
 def take_row_scan_job(device):
-    return _ROW_SCAN_JOB.pop(torch.device(device), None)
+    """The job of the latest raw forward on `device`, for a caller about to launch kernels on the CURRENT stream -- None if
+    there is none or if that forward ran on another stream (the hand-over relies on stream order and nothing else)."""
+    job = _ROW_SCAN_JOB.pop(torch.device(device), None)
+    if job is not None and job._stream != torch.cuda.current_stream(torch.device(device)).cuda_stream:
+        return None
+    return job
 
 
 def _pop_pending(device, model):
@@ -502,6 +507,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             _lib.check(L.gsr_row_scan_job(C.c_void_p(alloc.buffers[_lib.GSR_BUF_BINNING].data_ptr()), int(out.num_rendered),
                                           W, H, C.byref(job)))
             job._lease = alloc.kept            # keeps BINNING out of the pool while anybody may still write into it
+            job._stream = stream               # the hand-over is ordered by this stream and nothing else
             ctx.row_scan_job = job
             _ROW_SCAN_JOB[torch.device(device)] = job
         ctx.set_materialize_grads(False)     # no zero tensors for the unused radii / image gradients
@@ -557,6 +563,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             job = getattr(ctx, "row_scan_job", None)
             if _ROW_SCAN_JOB.get(torch.device(device)) is job:
                 _ROW_SCAN_JOB.pop(torch.device(device), None)        # nobody picked it up: the backward scans itself
+            if job is not None and job._stream != stream:    # not the stream the hand-over was ordered by: scan here
+                job = None
             if job is not None:
                 rc = L.gsr_backward_with_job(C.byref(view), C.byref(g), ctx.num_rendered, _ptr(radii), _ptr(geom),
                                              _ptr(binning), _ptr(image), _ptr(grad_color), _ptr(grad_allmap), C.byref(grads),
