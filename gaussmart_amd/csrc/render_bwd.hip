@@ -40,8 +40,21 @@
 // PROBE (developer builds only: make PROBES=1, scripts/dev_probe.py): 1 = eight more dependent VALU per iteration,
 // 4 = eight more dependent SALU, 3 = no row store (WRONG gradients: it exists to time the loop), 6 = 20 KB more LDS per
 // workgroup (fewer waves per SIMD), 8 = four LDS reads of the record instead of five (WRONG gradients).
+#ifdef GSR_DEV_PROBES
+// PROBE 7 (round 4): every wave leaves its lifetime on the shader clock (s_memtime) and on the 100 MHz s_memrealtime
+// clock: their ratio is the clock the chip holds under this kernel (scripts/dev_clock_probe.py).
+#define RB_STAMP_WAVES 65536
+__device__ unsigned long long g_rb_stamps[2 * RB_STAMP_WAVES];
+extern "C" int gsr_probe_read_stamps_bwd(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rb_stamps), bytes < sizeof(g_rb_stamps) ? bytes : sizeof(g_rb_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
 template <int PROBE = 0>
 __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(RenderBwdParams p) {
+#ifdef GSR_DEV_PROBES
+    unsigned long long stamp_t0 = 0, stamp_c0 = 0;
+    if (PROBE == 7) { stamp_t0 = __builtin_amdgcn_s_memrealtime(); stamp_c0 = __builtin_amdgcn_s_memtime(); }
+#endif
     __shared__ float s_probe_pad[PROBE == 6 ? 5120 : 1];
     if (PROBE == 6 && p.W < 0) s_probe_pad[threadIdx.x] = 1.f;
     __shared__ float4 s_rec_all[RB_WAVES][64 * 5];
@@ -292,6 +305,13 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
         __builtin_amdgcn_wave_barrier();   // all reads of this batch precede the next batch's LDS writes
         hi = lo;
     }
+#ifdef GSR_DEV_PROBES
+    if (PROBE == 7) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+        const uint32_t w = blockIdx.x * 4u + (uint32_t)wave;
+        if (lane == 0 && w < RB_STAMP_WAVES) { g_rb_stamps[2 * w] = c1 - stamp_c0; g_rb_stamps[2 * w + 1] = t1 - stamp_t0; }
+    }
+#endif
 }
 
 // Wide payload: add a Gaussian's feature rows (same dense slots as the geometry rows) in fixed order.  One thread
@@ -400,6 +420,7 @@ int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32
             case 3: hipLaunchKernelGGL((render_bwd_kernel<3>), grid, block, 0, s, p); break;
             case 4: hipLaunchKernelGGL((render_bwd_kernel<4>), grid, block, 0, s, p); break;
             case 6: hipLaunchKernelGGL((render_bwd_kernel<6>), grid, block, 0, s, p); break;
+            case 7: hipLaunchKernelGGL((render_bwd_kernel<7>), grid, block, 0, s, p); break;
             case 8: hipLaunchKernelGGL((render_bwd_kernel<8>), grid, block, 0, s, p); break;
             default: hipLaunchKernelGGL((render_bwd_kernel<>), grid, block, 0, s, p);
         }

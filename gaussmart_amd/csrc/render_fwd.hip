@@ -36,10 +36,12 @@
     } while (0)
 
 #ifdef GSR_DEV_PROBES
-// PROBE 7: every wave leaves (start, end) on the 100 MHz s_memrealtime clock and its hardware id -- the occupancy of a
-// launch over time (scripts/dev_wave_timeline.py).  Developer builds only.
+// PROBE 7: every wave leaves (start, end) on the 100 MHz s_memrealtime clock, its hardware id and (round 4) its start and
+// end on the shader clock (s_memtime) -- the occupancy of a launch over time (scripts/dev_wave_timeline.py) and the clock
+// the chip holds while the kernel runs (scripts/dev_clock_probe.py).  Developer builds only.
 #define RF_STAMP_WAVES 65536
-__device__ unsigned long long g_rf_stamps[3 * RF_STAMP_WAVES];
+#define RF_STAMP_WORDS 5
+__device__ unsigned long long g_rf_stamps[RF_STAMP_WORDS * RF_STAMP_WAVES];
 extern "C" int gsr_probe_read_stamps(void* dst, size_t bytes) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rf_stamps), bytes < sizeof(g_rf_stamps) ? bytes : sizeof(g_rf_stamps)) == hipSuccess ? 0 : -1;
 }
@@ -104,8 +106,8 @@ __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : (FEAT16
     // neighbouring tiles are fetched into ONE L2 instead of several
     const int tile_lin = (int)(blockIdx.x & 7u) * p.per_xcd + (int)(blockIdx.x >> 3);
 #ifdef GSR_DEV_PROBES
-    unsigned long long stamp_t0 = 0;
-    if (PROBE == 7) stamp_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long stamp_t0 = 0, stamp_c0 = 0;
+    if (PROBE == 7) { stamp_t0 = __builtin_amdgcn_s_memrealtime(); stamp_c0 = __builtin_amdgcn_s_memtime(); }
 #endif
     if (tile_lin >= p.n_tiles) return;
     __shared__ uint32_t s_waves_done, s_cov[RF_WAVES];
@@ -375,14 +377,15 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
     }
 #ifdef GSR_DEV_PROBES
     if (PROBE == 7) {
-        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
         uint32_t hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         const uint32_t w = blockIdx.x * 4u + (uint32_t)wave;
         if (lane == 0 && w < RF_STAMP_WAVES) {
-            g_rf_stamps[3 * w] = stamp_t0; g_rf_stamps[3 * w + 1] = t1;
-            g_rf_stamps[3 * w + 2] = ((unsigned long long)xcc << 32) | hw;
+            g_rf_stamps[RF_STAMP_WORDS * w] = stamp_t0; g_rf_stamps[RF_STAMP_WORDS * w + 1] = t1;
+            g_rf_stamps[RF_STAMP_WORDS * w + 2] = ((unsigned long long)xcc << 32) | hw;
+            g_rf_stamps[RF_STAMP_WORDS * w + 3] = stamp_c0; g_rf_stamps[RF_STAMP_WORDS * w + 4] = c1;
         }
     }
 #endif

@@ -19,7 +19,8 @@ from .fused_regularizer import camera_kinv
 
 class _Objective(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image, allmap, gt, kinv, lambda_dssim, lambda_normal, lambda_dist, depth_ratio, defer_value=False):
+    def forward(ctx, image, allmap, gt, kinv, lambda_dssim, lambda_normal, lambda_dist, depth_ratio, defer_value=False,
+                job=None):
         L = _lib.lib()
         if image.device.type != "cuda":
             raise _lib.GsrError("training_objective needs tensors on a HIP device (torch 'cuda'); there is no CPU path")
@@ -33,11 +34,15 @@ class _Objective(torch.autograd.Function):
             n_part = L.gsr_loss_num_partials(H, W)
             maps = torch.empty((3, Cn, H, W), dtype=torch.float32, device=dev)
             partials = torch.empty((2, n_part), dtype=torch.float32, device=dev)
-            out = torch.empty(5, dtype=torch.float32, device=dev)
+            # (with defer_value the five scalars are only written during the backward: until then they read NaN, so a value
+            # taken without a backward -- or before it -- is visibly invalid instead of uninitialised memory)
+            out = torch.full((5,), float("nan"), dtype=torch.float32, device=dev) if defer_value else \
+                torch.empty(5, dtype=torch.float32, device=dev)
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            # the scan the rasterizer's backward starts with rides along with these launches, if its forward offered it
-            from . import rasterizer as _rast
-            job = _rast.take_row_scan_job(dev) if (ctx.needs_input_grad[0] and hasattr(L, "gsr_loss_forward_job")) else None
+            # the scan the rasterizer's backward starts with rides along with these launches, if the forward that produced
+            # `image` offered it (training_objective took the job from image.grad_fn)
+            if not ctx.needs_input_grad[0]:
+                job = None
             ctx.row_scan_job = job
             if job is not None:
                 _lib.check(L.gsr_loss_forward_job(C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()), Cn, H, W,
@@ -50,8 +55,7 @@ class _Objective(torch.autograd.Function):
             # scalars are computed by a workgroup riding along with a kernel of the backward (gsr_loss_backward_finish), and
             # the regularizer's forward sums -- which only feed those scalars -- come from its backward kernel, which
             # evaluates every pixel's surface normal anyway (gsr_regularizer_backward_partials): no forward launch of it
-            defer = bool(defer_value and ctx.needs_input_grad[0] and hasattr(L, "gsr_loss_forward_job")
-                         and (not use_reg or (ctx.needs_input_grad[1] and hasattr(L, "gsr_regularizer_backward_partials"))))
+            defer = bool(defer_value and ctx.needs_input_grad[0] and (not use_reg or ctx.needs_input_grad[1]))
             reg_ptr = None
             if use_reg and not defer:
                 _lib.check(L.gsr_regularizer_forward(C.c_void_p(am.data_ptr()), H, W, kinv, float(depth_ratio),
@@ -80,7 +84,7 @@ class _Objective(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_parts):
         if g_total is None:
-            return (None,) * 9
+            return (None,) * 10
         L = _lib.lib()
         saved = ctx.saved_tensors
         img, tgt, maps = saved[0], saved[1], saved[2]
@@ -92,8 +96,13 @@ class _Objective(torch.autograd.Function):
             scale = g_total.detach().float().reshape(1).contiguous()
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             dimg = torch.empty_like(img)
+            from .rasterizer import row_scan_job_alive
             job = getattr(ctx, "row_scan_job", None)
             ctx.row_scan_job = None
+            # the second half may only be enqueued while the rasterizer's backward has not run (afterwards the job's
+            # buffers are back in the pool), and on the stream the first half was ordered on
+            if not row_scan_job_alive(job) or job._stream != torch.cuda.current_stream(dev).cuda_stream:
+                job = None
             deferred, ctx.deferred = ctx.deferred, None
             if ctx.use_reg:       # first: with a deferred value its launch also leaves the regularizer's forward sums
                 am = saved[3]
@@ -118,15 +127,19 @@ class _Objective(torch.autograd.Function):
                 _lib.check(L.gsr_loss_backward(C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()),
                                                C.c_void_p(maps.data_ptr()), Cn, H, W, ld, C.c_void_p(scale.data_ptr()),
                                                C.c_void_p(dimg.data_ptr()), stream))
-        return dimg, dam, None, None, None, None, None, None, None
+        return dimg, dam, None, None, None, None, None, None, None, None
 
 
 def training_objective(image, allmap, gt, viewpoint_camera, lambda_dssim=0.2, lambda_normal=0.0, lambda_dist=0.0,
                        depth_ratio=0.0, defer_value=False):
     """-> (total, parts) with parts = [l1, ssim, mean normal error, mean distortion] (device tensor).
     `defer_value`: for callers that call backward() right away and read the values only afterwards -- the five scalars
-    are then written during the backward (one launch less in the iteration); before it they are undefined."""
+    are then written during the backward (one launch less in the iteration); before it (or without it) they read NaN."""
     use_reg = allmap is not None and (lambda_normal > 0.0 or lambda_dist > 0.0)
     kinv = camera_kinv(viewpoint_camera) if use_reg else None
+    job = None
+    if image.is_cuda and image.requires_grad and torch.is_grad_enabled():
+        from .rasterizer import take_row_scan_job
+        job = take_row_scan_job(image)
     return _Objective.apply(image, allmap if use_reg else None, gt, kinv, lambda_dssim, lambda_normal, lambda_dist,
-                            depth_ratio, bool(defer_value))
+                            depth_ratio, bool(defer_value), job)

@@ -50,6 +50,10 @@ class GaussianModel:
         self.spatial_lr_scale = 0
         self.uniform_upsampling = uniform_upsampling
         self.use_fused_adam = True
+        # hand-over slots between the rasterizer operator and the optimiser step of THIS model (pending side-stream
+        # update, factored SH gradient): per model, nothing at module level
+        from .rasterizer import RasterState
+        self.raster_state = RasterState()
         self.setup_functions()
 
     # ------------------------------------------------------------------ checkpoint tuple

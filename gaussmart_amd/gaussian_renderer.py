@@ -128,6 +128,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
     raw = _use_raw_path(pc, pipe, override_color, xyz)
+    # the model's hand-over slots with the optimiser step (rasterizer.RasterState): a pipelined step may still be updating
+    # the SH tensors on a side stream -- the raw forward orders its colour pass behind that itself, everything else that
+    # reads the parameters (the torch activations below) waits here
+    state = getattr(pc, "raster_state", None)
+    if state is not None and not raw and xyz.is_cuda:
+        state.wait_pending(device)
     means3D, means2D = xyz, screenspace_points
     opacity = None if raw else pc.get_opacity
     scales = rotations = cov3D_precomp = None
@@ -165,7 +171,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             cache = lookup(viewpoint_camera.camera_center, pc.active_sh_degree, pc._xyz, pc._features_dc, pc._features_rest)
         rendered_image, radii, allmap = rasterize_gaussians_raw(
             xyz, means2D, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation, raster_settings,
-            factored_sh_grad=factored, color_cache=cache)
+            factored_sh_grad=factored and state is not None, color_cache=cache if state is not None else None, state=state)
     else:
         rendered_image, radii, allmap = rasterizer(
             means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,

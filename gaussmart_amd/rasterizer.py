@@ -104,6 +104,8 @@ class _BufferPool:
         if lst:                                   # too small: let the largest one go, grow once
             lst.sort(key=lambda t: t.numel())
             lst.pop()
+        STATS["pool_buffers_created"] += 1
+        STATS["pool_bytes_created"] += _round_up(nbytes + nbytes // 4, 1 << 22)
         if _POOL_DEBUG:
             print(f"[gsr pool] new buffer kind {key[2]}: need {nbytes / 2**20:.1f} MiB (had {[round(t.numel() / 2**20, 1) for t in lst]})", flush=True)
         return torch.empty(_round_up(nbytes + nbytes // 4, 1 << 22), dtype=torch.uint8, device=device)
@@ -117,7 +119,9 @@ class _BufferPool:
 
 _POOL = _BufferPool()
 STATS = {"color_pass_on_second_stream": 0,     # how often a forward put its SH colour pass on the updater's stream
-         "row_scans_carried": 0}               # how often a backward found its row scan done by the objective's kernels
+         "row_scans_carried": 0,               # how often a backward found its row scan done by the objective's kernels
+         "pool_buffers_created": 0,            # grow-only workspace: buffers the pool had to create (first use or re-grow)
+         "pool_bytes_created": 0}
 _POOL_DEBUG = bool(__import__("os").environ.get("GSR_POOL_DEBUG"))
 
 
@@ -203,66 +207,6 @@ def _finish_lease(ctx):
         ctx.lease.release()
 
 
-# Pipelined data-parallel step (view_parallel.py): the SH parameters may still be receiving their Adam update on a
-# side stream when the next forward starts.  The event that marks the end of that update is parked here; the raw
-# forward lets its geometry / binning phase run and makes the stream wait right before the SH colour pass
-# (GSR_FLAG_DEFER_COLOR: the pass is enqueued after binning, announced through the allocator); every other consumer
-# waits up front.
-_PENDING_PARAM_EVENT = {}     # (device, model key) -> (event, stream); model key = data_ptr of the model's xyz parameter
-
-
-def _model_key(xyz):
-    """Identity of a model for the module-level hand-over slots: the storage address of its position parameter (two
-    models on one device never share it; a densification that replaces the tensor also retires the stale slot)."""
-    return None if xyz is None else int(xyz.data_ptr())
-
-
-def set_pending_param_event(device, event, stream=None, model=None):
-    """`event`: end of the SH update; `stream`: the stream it runs on -- the next raw forward OF THAT MODEL (`model` =
-    its xyz parameter) then puts its SH colour pass on that stream too (GSR_BUF_COLOR_STREAM), behind the update, while
-    its own stream sorts and bins.  Forwards of other models on the same device are not affected."""
-    _PENDING_PARAM_EVENT[(torch.device(device), _model_key(model))] = (event, stream)
-
-
-# Row-scan side job (include/gsr.h: GsrRowScanJob): the raw forward describes the scan its backward starts with and parks
-# the description here; the fused objective, whose kernels run between the two, picks it up and carries the scan in
-# extra workgroups of its own launches.  The job holds the forward's buffer lease, so the buffers outlive the kernels
-# that write into them whatever happens to the autograd graph.  GSR_ROW_SCAN_RIDE=0 switches the hand-over off.
-_ROW_SCAN_JOB = {}            # device -> job of the latest raw forward that kept its buffers for a backward
-_ROW_SCAN_RIDE = __import__("os").environ.get("GSR_ROW_SCAN_RIDE", "1") != "0"
-
-
-def take_row_scan_job(device):
-    """The job of the latest raw forward on `device`, for a caller about to launch kernels on the CURRENT stream -- None if
-    there is none or if that forward ran on another stream (the hand-over relies on stream order and nothing else)."""
-    job = _ROW_SCAN_JOB.pop(torch.device(device), None)
-    if job is not None and job._stream != torch.cuda.current_stream(torch.device(device)).cuda_stream:
-        return None
-    return job
-
-
-def _pop_pending(device, model):
-    device = torch.device(device)
-    pend = _PENDING_PARAM_EVENT.pop((device, _model_key(model)), None)
-    if pend is None and model is not None:       # parked without a model key (legacy callers): belongs to whoever runs next
-        pend = _PENDING_PARAM_EVENT.pop((device, None), None)
-    return pend
-
-
-def wait_pending_params(device, model=None):
-    """Make the current stream wait for outstanding side-stream parameter updates (no-op if there are none): the one
-    of `model` (its xyz parameter), or -- without a model, for callers that only hold derived tensors -- every update
-    pending on the device."""
-    device = torch.device(device)
-    if model is not None:
-        pend = _pop_pending(device, model)
-        if pend is not None:
-            torch.cuda.current_stream(device).wait_event(pend[0])
-        return
-    for key in [k for k in _PENDING_PARAM_EVENT if k[0] == device]:
-        torch.cuda.current_stream(device).wait_event(_PENDING_PARAM_EVENT.pop(key)[0])
-
-
 class ColorGradRecord:
     """Factored SH gradient of ONE backward (GSR_FLAG_FACTORED_SH_GRAD): instead of dL/d(features_dc) and
     dL/d(features_rest) -- 48 floats per Gaussian -- the backward leaves the clamp-masked colour gradient [N,3]
@@ -279,30 +223,69 @@ class ColorGradRecord:
         self.exchanged, self.gathered, self.n_views, self.grad_scale = False, None, 1, 1.0
 
 
-_COLOR_GRAD = {}     # (device, model key) -> ColorGradRecord of that model's last factored backward
+class RasterState:
+    """The hand-over slots between the raw-parameter operator and whoever owns the optimiser step of ONE model.  One
+    object per model (GaussianModel.raster_state), passed to rasterize_gaussians_raw(state=...): nothing is parked at module
+    level, so two models on one device -- or two threads with a model each -- cannot see each other's slots
+    (re-entrant, no global mutable state).
+
+    `pending`: pipelined data-parallel step (view_parallel.py) -- the SH parameters may still be receiving their Adam
+    update on a side stream when the next forward starts.  (event marking the end of that update, the stream it runs
+    on): the next raw forward given this state lets its geometry / binning phase run, puts its SH colour pass on that
+    stream too (GSR_FLAG_DEFER_COLOR + GSR_BUF_COLOR_STREAM), behind the update, or -- without a second stream -- makes
+    its own stream wait right before the colour pass.  Every other consumer of the parameters calls wait_pending() first.
+    `color_grad`: the ColorGradRecord the last factored backward of a forward given this state left."""
+    __slots__ = ("pending", "color_grad")
+
+    def __init__(self):
+        self.pending = None
+        self.color_grad = None
+
+    def set_pending_param_event(self, event, stream=None):
+        self.pending = (event, stream)
+
+    def pop_pending(self):
+        pend, self.pending = self.pending, None
+        return pend
+
+    def wait_pending(self, device):
+        """Make the current stream of `device` wait for an outstanding side-stream parameter update (no-op if none)."""
+        pend = self.pop_pending()
+        if pend is not None:
+            torch.cuda.current_stream(torch.device(device)).wait_event(pend[0])
+
+    def take_color_grad(self):
+        rec, self.color_grad = self.color_grad, None
+        return rec
 
 
-def _store_color_grad(device, xyz, rec):
-    """Most recent record LAST (a re-assigned dict key keeps its old position, so pop first), and slots whose model is
-    gone -- the xyz tensor they were keyed by was replaced by a densification and freed -- are retired with their
-    streams / events instead of accumulating."""
-    key = (device, _model_key(xyz))
-    _COLOR_GRAD.pop(key, None)
-    for k in [k for k, r in _COLOR_GRAD.items() if k[0] == device and (r.xyz is None or r.xyz.data_ptr() != k[1])]:
-        _COLOR_GRAD.pop(k, None)
-        _PENDING_PARAM_EVENT.pop(k, None)
-    _COLOR_GRAD[key] = rec
+# Row-scan side job (include/gsr.h: GsrRowScanJob): the raw forward describes the scan its backward starts with and keeps
+# the description ON ITS AUTOGRAD NODE; the fused objective, whose kernels run between the forward and the backward, finds
+# it through the grad_fn of the image it was handed -- so a job only ever rides with an objective of the image THAT forward
+# produced -- and carries the scan in extra workgroups of its own launches.  The job holds the forward's buffer lease until
+# the rasterizer's backward has consumed it; that backward marks it dead, so a kernel that would write into BINNING after
+# the buffers went back to the pool (an objective whose backward runs later, or twice) is never launched.
+# GSR_ROW_SCAN_RIDE=0 switches the hand-over off.
+_ROW_SCAN_RIDE = __import__("os").environ.get("GSR_ROW_SCAN_RIDE", "1") != "0"
 
 
-def take_color_grad(model_or_device):
-    """The ColorGradRecord the last factored backward left (None if there was none); clears the slot.  Pass the model's
-    xyz parameter: records are kept per model, so two models training on one device do not see each other's.  A device
-    (legacy) returns the most recent record on it."""
-    if isinstance(model_or_device, torch.Tensor):
-        return _COLOR_GRAD.pop((model_or_device.device, _model_key(model_or_device)), None)
-    device = torch.device(model_or_device)
-    keys = [k for k in _COLOR_GRAD if k[0] == device]
-    return _COLOR_GRAD.pop(keys[-1], None) if keys else None
+def take_row_scan_job(image):
+    """The row-scan job of the forward that produced `image` (one of its outputs, not a tensor derived from them), for a
+    caller about to launch kernels on the CURRENT stream -- None if that forward offered none, if somebody already took
+    it, if its backward already ran, or if the forward ran on another stream (the hand-over relies on stream order and
+    nothing else)."""
+    job = getattr(getattr(image, "grad_fn", None), "row_scan_job", None)
+    if job is None or job._taken or job._dead:
+        return None
+    if job._stream != torch.cuda.current_stream(image.device).cuda_stream:
+        return None
+    job._taken = True
+    return job
+
+
+def row_scan_job_alive(job):
+    """False once the rasterizer's backward has consumed the job (its buffers may be back in the pool)."""
+    return job is not None and not job._dead
 
 
 def release_workspace():
@@ -339,7 +322,6 @@ class _RasterizeGaussians(torch.autograd.Function):
         if device.type != "cuda":
             raise _lib.GsrError("GaussianRasterizer needs tensors on a HIP device (torch 'cuda'); "
                                 "there is no CPU path")
-        wait_pending_params(device)
         rs = raster_settings
         N = means3D.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
@@ -452,7 +434,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings, flags,
-                color_cache=None):
+                color_cache=None, state=None):
         L = _lib.lib()
         device = xyz.device
         if device.type != "cuda":
@@ -471,7 +453,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             if color_cache.numel() != 13 * N or color_cache.dtype != torch.float32 or color_cache.device != device:
                 raise ValueError("color_cache must be float32 [13 N] on the parameters' device")
             flags |= _lib.GSR_FLAG_COLOR_CACHED
-        pending = _pop_pending(device, xyz)
+        pending = state.pop_pending() if state is not None else None
         hook = color_stream = None
         if pending is not None:
             flags |= _lib.GSR_FLAG_DEFER_COLOR
@@ -501,15 +483,16 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         ctx.raster_settings, ctx.flags, ctx.num_rendered, ctx.M = rs, flags & ~_lib.GSR_FLAG_DEFER_COLOR, int(out.num_rendered), M
         ctx.view_keep = keep
         ctx.color_cache = color_cache        # (the backward reads d(rgb)/d(dir) from it)
+        ctx.state = state                    # (the backward leaves the factored SH gradient there)
         ctx.row_scan_job = None
-        if _ROW_SCAN_RIDE and hasattr(L, "gsr_row_scan_job") and int(out.num_rendered) > 0:
+        if _ROW_SCAN_RIDE and int(out.num_rendered) > 0:
             job = _lib.GsrRowScanJob()
             _lib.check(L.gsr_row_scan_job(C.c_void_p(alloc.buffers[_lib.GSR_BUF_BINNING].data_ptr()), int(out.num_rendered),
                                           W, H, C.byref(job)))
             job._lease = alloc.kept            # keeps BINNING out of the pool while anybody may still write into it
             job._stream = stream               # the hand-over is ordered by this stream and nothing else
-            ctx.row_scan_job = job
-            _ROW_SCAN_JOB[torch.device(device)] = job
+            job._taken = job._dead = False
+            ctx.row_scan_job = job             # found by the objective through image.grad_fn (take_row_scan_job)
         ctx.set_materialize_grads(False)     # no zero tensors for the unused radii / image gradients
         ctx.save_for_backward(xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, radii,
                               alloc.buffers[_lib.GSR_BUF_GEOM], alloc.buffers[_lib.GSR_BUF_BINNING],
@@ -561,16 +544,19 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             alloc = _Allocator(device)
             stream = torch.cuda.current_stream(device).cuda_stream
             job = getattr(ctx, "row_scan_job", None)
-            if _ROW_SCAN_JOB.get(torch.device(device)) is job:
-                _ROW_SCAN_JOB.pop(torch.device(device), None)        # nobody picked it up: the backward scans itself
-            if job is not None and job._stream != stream:    # not the stream the hand-over was ordered by: scan here
-                job = None
+            if job is not None:
+                # whatever happens below, nobody may enqueue a half of this job any more: after this backward the buffers
+                # go back to the pool (an objective holding the job checks row_scan_job_alive before it launches)
+                usable = not job._dead and job._stream == stream      # else: not the stream the hand-over was ordered by
+                job._dead = True
+                job._lease = None
+                if not usable:
+                    job = None
             if job is not None:
                 rc = L.gsr_backward_with_job(C.byref(view), C.byref(g), ctx.num_rendered, _ptr(radii), _ptr(geom),
                                              _ptr(binning), _ptr(image), _ptr(grad_color), _ptr(grad_allmap), C.byref(grads),
                                              C.byref(job), alloc.cb, None, C.c_void_p(stream))
                 STATS["row_scans_carried"] += int(job.stage == 2)
-                job._lease = None
             else:
                 rc = L.gsr_backward(C.byref(view), C.byref(g), ctx.num_rendered, _ptr(radii), _ptr(geom), _ptr(binning),
                                     _ptr(image), _ptr(grad_color), _ptr(grad_allmap), C.byref(grads), alloc.cb, None,
@@ -582,9 +568,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         del keep
         _finish_lease(ctx)
         if factored:
-            _store_color_grad(torch.device(device), xyz, ColorGradRecord(flat, flat[:n_head], record, N, ctx.M,
-                                                                          rs.sh_degree, xyz))
-        return d_xyz, d_2d, d_dc, d_rest, d_op, d_sc, d_rot, None, None, None
+            ctx.state.color_grad = ColorGradRecord(flat, flat[:n_head], record, N, ctx.M, rs.sh_degree, xyz)
+        return d_xyz, d_2d, d_dc, d_rest, d_op, d_sc, d_rot, None, None, None, None
 
 
 def _wants_grad(*tensors):
@@ -598,7 +583,6 @@ def _forward_only(device, rs, flags, sh_coeffs, gaussians_args, N):
     L = _lib.lib()
     if device.type != "cuda":
         raise _lib.GsrError("GaussianRasterizer needs tensors on a HIP device (torch 'cuda'); there is no CPU path")
-    wait_pending_params(device)
     H, W = int(rs.image_height), int(rs.image_width)
     with torch.cuda.device(device):
         view, keep = _make_view(rs, sh_coeffs, int(flags) | _lib.GSR_FLAG_FORWARD_ONLY, device)
@@ -620,13 +604,20 @@ def _forward_only(device, rs, flags, sh_coeffs, gaussians_args, N):
 
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
-                            raster_settings, flags=None, factored_sh_grad=False, color_cache=None):
+                            raster_settings, flags=None, factored_sh_grad=False, color_cache=None, state=None):
     """(color, radii, allmap) from the model's raw parameter tensors; activations fused in-kernel.
-    `factored_sh_grad`: the backward leaves NO gradient on features_dc / features_rest; it parks a ColorGradRecord
-    (take_color_grad) for FusedAdam.step_sh_factored instead -- only for callers that own the optimiser step."""
+    `state`: the model's RasterState (hand-over slots with the optimiser step); None for a caller that has neither a
+    pipelined update in flight nor a factored gradient to receive.
+    `factored_sh_grad`: the backward leaves NO gradient on features_dc / features_rest; it leaves a ColorGradRecord in
+    `state.color_grad` (RasterState.take_color_grad) for FusedAdam.step_sh_factored instead -- only for callers that own
+    the optimiser step, and only with a `state` to leave it in."""
     flags = DEFAULT_FLAGS if flags is None else flags
+    if factored_sh_grad and state is None:
+        raise ValueError("factored_sh_grad needs state=RasterState(): the backward leaves its colour-gradient record there")
     if not _wants_grad(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw):
         device = xyz.device
+        if state is not None:
+            state.wait_pending(device)
         args = [_f32c(t, n, device) for t, n in ((xyz, "xyz"), (features_dc, "features_dc"), (None, ""), (opacity_raw, "opacity"),
                                                  (scaling_raw, "scaling"), (rotation_raw, "rotation"), (None, ""))]
         rest = _f32c(features_rest, "features_rest", device)
@@ -638,7 +629,8 @@ def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_ra
     if factored_sh_grad:
         flags |= _lib.GSR_FLAG_FACTORED_SH_GRAD
     return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
-                                        rotation_raw, raster_settings, flags, color_cache if factored_sh_grad else None)
+                                        rotation_raw, raster_settings, flags, color_cache if factored_sh_grad else None,
+                                        state)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,

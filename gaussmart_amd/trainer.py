@@ -13,7 +13,6 @@ import torch
 
 from .gaussian_renderer import render
 from .fused_adam import FusedAdam
-from .rasterizer import take_color_grad
 from .fused_loss import photometric_loss as fused_photometric_loss
 from .fused_objective import training_objective
 from .losses import l1_loss, ssim
@@ -66,6 +65,7 @@ def _use_factored_sh_grad(gaussians, pipe, render_fn, on_device):
     """The backward may leave dL/drgb [N,3] instead of the SH gradient tensors only when this module also performs the
     optimiser step with the kernel that understands it (FusedAdam.step_sh_factored) on the raw-parameter path."""
     return (on_device and render_fn is render and getattr(pipe, "factored_sh_grad", False)
+            and getattr(gaussians, "raster_state", None) is not None
             and getattr(pipe, "fused_activations", False) and isinstance(getattr(gaussians, "optimizer", None), FusedAdam))
 
 
@@ -103,7 +103,7 @@ def training_step(gaussians, viewpoint_cam, gt_image, opt, pipe, background, ite
     # their own -- nobody reads them before this function returns)
     total, parts = training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam, pipe, defer_value=True)
     total.backward(gradient=_unit_gradient(total))   # cached: saves the ones_like() fill of every step
-    rec = take_color_grad(gaussians._xyz) if factored else None
+    rec = gaussians.raster_state.take_color_grad() if factored else None
     if factored:
         gaussians.optimizer.park_sh_gradient(gaussians._features_dc, gaussians._features_rest, rec)
     if step_optimizer:

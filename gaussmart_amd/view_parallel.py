@@ -245,7 +245,7 @@ class ViewParallel:
         # Pipelined: the main stream waits only for the 40 MB geometry all-reduce, updates xyz / opacity / scaling /
         # rotation and starts the next forward; the all-gather of the colour gradients and the SH update run on the
         # side stream against a snapshot of the positions, and the next forward puts its SH colour pass behind them on
-        # that stream (rasterizer.set_pending_param_event).  With `overlap_local` the same overlap is used without any
+        # that stream (RasterState.set_pending_param_event).  With `overlap_local` the same overlap is used without any
         # exchange: the bandwidth-bound SH update runs beside the latency-bound sorting / binning of the next forward.
         from . import rasterizer
         dev = rec.head.device
@@ -279,7 +279,7 @@ class ViewParallel:
             ev.record(self._side)
         rec.flat.record_stream(self._side)
         self._pending = ev
-        rasterizer.set_pending_param_event(dev, ev, self._side, model=self.g._xyz)
+        self._raster_state().set_pending_param_event(ev, self._side)
 
     def reduce_and_step(self, optimizer, rec=None):
         """all-reduce + optimiser step of one iteration.  `rec`: the factored SH gradient of this iteration's backward
@@ -290,7 +290,7 @@ class ViewParallel:
         waits for the first: it updates xyz / f_dc / opacity / scaling / rotation and is free to start the next
         forward, whose geometry, sorting and binning phase (~0.4 ms at 1 M Gaussians) does not read the SH
         coefficients.  The second collective and the Adam update of f_rest run on a side stream; the next forward
-        waits for them right before its SH colour pass (rasterizer.set_pending_param_event).  Anything else that
+        waits for them right before its SH colour pass (RasterState.set_pending_param_event).  Anything else that
         touches the parameters must call finish() first (densification, saving, evaluation renders do).
         Falls back to allreduce_gradients() + optimizer.step() whenever a precondition is missing."""
         if rec is not None:
@@ -345,14 +345,21 @@ class ViewParallel:
             ev.record(self._side)
         flat.record_stream(self._side)                    # its memory may be reused only after the side stream is done
         self._pending = ev
-        rasterizer.set_pending_param_event(dev, ev, self._side, model=self.g._xyz)
+        self._raster_state().set_pending_param_event(ev, self._side)
+
+    def _raster_state(self):
+        """The model's hand-over slots with the operator (rasterizer.RasterState); created on models that lack one."""
+        st = getattr(self.g, "raster_state", None)
+        if st is None:
+            from .rasterizer import RasterState
+            st = self.g.raster_state = RasterState()
+        return st
 
     def finish(self):
         """Make the current stream wait for the outstanding SH update of a pipelined step, if any."""
         if self._pending is not None:
-            from . import rasterizer
             dev = self.g.parameters()[0].device
-            rasterizer.wait_pending_params(dev, model=self.g._xyz)   # un-park it (no-op if a forward consumed it)
+            self._raster_state().pop_pending()                     # un-park it (no-op if a forward consumed it)
             torch.cuda.current_stream(dev).wait_event(self._pending)
             self._pending = None
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 4
+#define GSR_ABI_VERSION 5   /* 5: BINNING carries row_count / slot_off / the scan workspace, 72-byte gradient rows, GsrRowScanJob */
 #define GSR_MAX_CHANNELS 64   /* widest per-pixel payload of gsr_forward / gsr_backward */
 
 typedef void* gsr_stream_t; /* hipStream_t */

@@ -35,17 +35,19 @@ lib = _lib.lib()
 n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
 per_xcd = (n_tiles + 7) // 8
 n_waves = 8 * per_xcd * 4
-buf = np.zeros(3 * n_waves, dtype=np.uint64)
+buf = np.zeros(5 * n_waves, dtype=np.uint64)
 lib.gsr_probe_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 rc = lib.gsr_probe_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes)
 assert rc == 0
-st = buf.reshape(-1, 3)
+st = buf.reshape(-1, 5)
 ok = st[:, 1] > 0
 t0, t1, hid = st[ok, 0].astype(np.int64), st[ok, 1].astype(np.int64), st[ok, 2]
 base = t0.min()
 t0 = (t0 - base) / 100.0; t1 = (t1 - base) / 100.0          # microseconds
 dur = t1 - t0
 span = t1.max()
+cyc = (st[ok, 4].astype(np.int64) - st[ok, 3].astype(np.int64)).sum()
+print(f"shader clock held during the launch: {cyc / (dur.sum() * 100.0) * 100.0:.0f} MHz (sum of s_memtime spans / sum of s_memrealtime spans)")
 print(f"{name} r={r}: {ok.sum()} waves, launch span {span:.1f} us; wave duration mean {dur.mean():.1f} us, "
       f"p10 {np.percentile(dur, 10):.1f}, median {np.median(dur):.1f}, p90 {np.percentile(dur, 90):.1f}, max {dur.max():.1f}")
 print(f"sum of wave durations / (span x 7168 slots) = {dur.sum() / (span * 7168):.3f}")

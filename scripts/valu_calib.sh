@@ -9,7 +9,7 @@ out=gpurun_out/valu_calib
 mkdir -p $out
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value $mb/valu_rate.hip -o $mb/valu_rate || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -S --cuda-device-only $mb/valu_rate.hip -o $out/valu_rate.s || exit 1
-echo "== disassembly check (occurrences inside the five loops; 8 each, 8 + 8 for compare + select)"
+echo "== disassembly check (occurrences in the file: the five calibration loops hold 8 each, 8 + 8 for compare + select; the round-4 kinds add 4 + 4 v_fma_f32, 4 v_add_f32_dpp, 8 + 4 v_cndmask_b32, 8 v_cmp_gt_f32)"
 for k in v_fma_f32 v_pk_fma_f32 v_cmp_gt_f32 v_cndmask_b32 v_rcp_f32 v_add_f32_dpp; do echo "$k $(grep -c "^\s*$k" $out/valu_rate.s)"; done | tee $out/disasm_counts.txt
 echo "== timing"
 $mb/valu_rate | tee $out/rates.txt
@@ -26,10 +26,13 @@ for f in glob.glob(out + "/pmc/**/*counter_collection.csv", recursive=True):
 expected, rates = {}, {}
 names = {"v_fma_f32": 0, "v_pk_fma_f32": 1, "v_cmp+v_cndmask": 2, "v_rcp_f32": 3, "v_add_f32": 4}
 for line in open(out + "/rates.txt"):
-    m = re.match(r"(\S+(?: dpp)?)\s+([\d.]+) ms\s+([\d.]+) G wave-instr/s\s+= ([\d.]+) cycles.*per launch (\d+)", line)
+    m = re.match(r"(\S+(?: dpp)?)\s+([\d.]+) ms\s+([\d.]+) G wave-instr/s\s+clock\s+(\d+) MHz\s+= ([\d.]+) cycles.*in-wave stamps: ([\d.]+); ([\d.]+) at the nominal.*per launch (\d+)", line)
     if m:
         kind = names[m.group(1).split()[0]]
-        expected[kind] = float(m.group(5)); rates[kind] = {"name": m.group(1), "ms": float(m.group(2)), "g_wave_instr_s": float(m.group(3)), "cycles_per_instr_per_simd": float(m.group(4))}
+        expected[kind] = float(m.group(8))
+        rates[kind] = {"name": m.group(1), "ms": float(m.group(2)), "g_wave_instr_s": float(m.group(3)), "clock_mhz": float(m.group(4)),
+                       "cycles_per_instr_per_simd": float(m.group(5)), "cycles_per_instr_per_simd_in_wave_stamps": float(m.group(6)),
+                       "cycles_per_instr_per_simd_at_2400mhz": float(m.group(7))}
 res = {}
 for k, v in sorted(acc.items()):
     kind = int(re.search(r"<(\d)>", k).group(1))

@@ -35,7 +35,6 @@ def test_cached_colour_equals_the_colour_pass(gpu_device):
     the ordinary colour pass (same formulas, other summation order) and the same gradients."""
     from gaussmart_amd.gaussian_renderer import render
     from gaussmart_amd.trainer import training_step
-    from gaussmart_amd.rasterizer import take_color_grad
     fresh, cams, gts, pipe, opt, bg = _setup(gpu_device)
     m = fresh()
     training_step(m, cams[0], gts[0], opt, pipe, bg, 10000, next_cam=cams[1])
@@ -54,7 +53,7 @@ def test_cached_colour_equals_the_colour_pass(gpu_device):
             o.color_cache = None                     # render() looks it up itself
         pkg = render(cams[1], m, pipe, bg, surface_maps=False, factored_sh_grad=True)
         ((pkg["render"] - gts[1]).square().sum() + pkg["allmap"][0].sum() * 1e-3).backward()
-        rec = take_color_grad(m._xyz)
+        rec = m.raster_state.take_color_grad()
         o.color_cache = saved
         return pkg["render"].detach().clone(), pkg["allmap"].detach().clone(), [p.grad.clone() for p in m.parameters()
                                                                                  if p.grad is not None], rec.record.clone()

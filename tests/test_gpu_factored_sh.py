@@ -29,13 +29,14 @@ def _backward(gpu_device, p, cam, factored, deg=3):
     for v in p.values():
         v.grad = None
     m2d = torch.zeros_like(p["xyz"], requires_grad=True)
+    state = R.RasterState()      # the per-model hand-over slots: the factored backward leaves its record there
     color, radii, allmap = R.rasterize_gaussians_raw(p["xyz"], m2d, p["features_dc"], p["features_rest"], p["opacity"],
-                                                     p["scaling"], p["rotation"], rs, factored_sh_grad=factored)
+                                                     p["scaling"], p["rotation"], rs, factored_sh_grad=factored, state=state)
     gen = torch.Generator().manual_seed(11)
     wc = torch.randn(color.shape, generator=gen).to(gpu_device)
     wa = torch.randn(allmap.shape, generator=gen).to(gpu_device) * 0.1
     ((color * wc).sum() + (allmap * wa).sum()).backward()
-    return R.take_color_grad(gpu_device), radii
+    return state.take_color_grad(), radii
 
 
 def _sh_grad_from_record(xyz, record, n, deg, coeffs=16):

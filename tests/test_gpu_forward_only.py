@@ -74,7 +74,6 @@ def test_two_models_on_one_device_do_not_share_state(gpu_device):
     from gaussmart_amd.gaussian_renderer import render
     from gaussmart_amd.params import OptimizationParams, PipelineParams
     from gaussmart_amd.trainer import training_losses, optimizer_step
-    from gaussmart_amd.rasterizer import take_color_grad
     dev = gpu_device
     w, h = 320, 200
     pipe, opt, bg = PipelineParams(), OptimizationParams(), torch.zeros(3, device=dev)
@@ -103,7 +102,7 @@ def test_two_models_on_one_device_do_not_share_state(gpu_device):
         return total
 
     def finish(m):
-        rec = take_color_grad(m._xyz)
+        rec = m.raster_state.take_color_grad()
         assert rec is not None and rec.n == m._xyz.shape[0]
         m.optimizer.park_sh_gradient(m._features_dc, m._features_rest, rec)
         optimizer_step(m)

@@ -1,0 +1,220 @@
+"""The hand-overs between the raw-parameter operator, the fused objective and the optimiser step (re-entrant,
+no global mutable state): the row-scan job rides only with an objective of the image ITS forward produced, only on the
+stream it was ordered on, and never after the rasterizer's backward has given the buffers back; the per-model slots
+(rasterizer.RasterState) live on the model.  Every case must give the gradients of the plain path bit for bit."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(dev, n=30000, w=400, h=240, seed=11, view=1):
+    from gaussmart_amd.gaussian_model import GaussianModel
+    from gaussmart_amd.gaussian_renderer import render
+    from gaussmart_amd.params import OptimizationParams, PipelineParams
+    from gaussmart_amd.synthetic import make_scene, perturb, jittered_cameras
+    params, _ = make_scene(n, w, h, seed=seed)
+    cam = jittered_cameras(3, w, h, seed=seed, device=dev, amount=0.3)[view]
+    pipe, opt, bg = PipelineParams(), OptimizationParams(), torch.zeros(3, device=dev)
+    tgt = GaussianModel(3, device=dev)
+    tgt.create_from_params(perturb(params))
+    with torch.no_grad():
+        gt = render(cam, tgt, pipe, bg)["render"].clamp(0, 1).contiguous()
+
+    def fresh():
+        m = GaussianModel(3, device=dev)
+        m.create_from_params(params)
+        m.training_setup(opt)
+        return m
+    return fresh, cam, gt, pipe, opt, bg
+
+
+def _grads(m):
+    return [p.grad.clone() for p in m.parameters() if p.grad is not None]
+
+
+def _reference(dev, fresh, cam, gt, pipe, opt, bg, monkeypatch, extra=None):
+    """Gradients of objective(render(model)) (+ `extra`(pkg)) with the hand-over switched off."""
+    from gaussmart_amd import rasterizer as R
+    from gaussmart_amd.gaussian_renderer import render
+    from gaussmart_amd.trainer import training_losses
+    monkeypatch.setattr(R, "_ROW_SCAN_RIDE", False)
+    m = fresh()
+    pkg = render(cam, m, pipe, bg, surface_maps=False)
+    total, _ = training_losses(pkg, gt, opt, 10000, cam, pipe)
+    if extra is not None:
+        total = total + extra(pkg)
+    total.backward()
+    torch.cuda.synchronize()
+    monkeypatch.setattr(R, "_ROW_SCAN_RIDE", True)
+    return _grads(m), total.detach().clone()
+
+
+def test_forward_and_objective_on_different_streams(gpu_device, monkeypatch):
+    """Forward on stream A, objective + backward on stream B: the job is declined (the hand-over is ordered by ONE stream
+    and nothing else), the backward scans itself, same bits."""
+    from gaussmart_amd import rasterizer as R
+    from gaussmart_amd.gaussian_renderer import render
+    from gaussmart_amd.trainer import training_losses
+    dev = gpu_device
+    fresh, cam, gt, pipe, opt, bg = _scene(dev)
+    ref, ref_total = _reference(dev, fresh, cam, gt, pipe, opt, bg, monkeypatch)
+    m = fresh()
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    before = R.STATS["row_scans_carried"]
+    with torch.cuda.stream(sa):
+        pkg = render(cam, m, pipe, bg, surface_maps=False)
+    job = pkg["render"].grad_fn.row_scan_job
+    assert job is not None and job._stream == sa.cuda_stream
+    sb.wait_stream(sa)
+    with torch.cuda.stream(sb):
+        total, _ = training_losses(pkg, gt, opt, 10000, cam, pipe)
+        assert not job._taken                          # declined: another stream
+        total.backward()
+    torch.cuda.synchronize()
+    assert R.STATS["row_scans_carried"] == before and job._dead
+    for a, b in zip(_grads(m), ref):
+        assert torch.equal(a, b)
+    assert torch.equal(total.detach(), ref_total)
+
+
+def test_two_models_interleaved_on_one_stream(gpu_device, monkeypatch):
+    """forward A, forward B, objective(A), objective(B), backward B, backward A: each objective carries the job of ITS
+    image's forward (round 3 handed out "the latest forward on the device"); both equal their solo runs bit for bit."""
+    from gaussmart_amd import rasterizer as R
+    from gaussmart_amd.gaussian_renderer import render
+    from gaussmart_amd.trainer import training_losses
+    dev = gpu_device
+    sa = _scene(dev, n=30000, seed=11, view=1)
+    sb = _scene(dev, n=21000, seed=12, view=2)
+    refs = [_reference(dev, *s, monkeypatch) for s in (sa, sb)]
+    ma, mb = sa[0](), sb[0]()
+    before = R.STATS["row_scans_carried"]
+    pa = render(sa[1], ma, sa[3], sa[5], surface_maps=False)
+    pb = render(sb[1], mb, sb[3], sb[5], surface_maps=False)
+    ja, jb = pa["render"].grad_fn.row_scan_job, pb["render"].grad_fn.row_scan_job
+    assert ja is not jb
+    ta, _ = training_losses(pa, sa[2], sa[4], 10000, sa[1], sa[3])
+    assert ja._taken and not jb._taken                 # A's objective took A's job, not the latest one
+    tb, _ = training_losses(pb, sb[2], sb[4], 10000, sb[1], sb[3])
+    assert jb._taken
+    tb.backward()
+    ta.backward()
+    torch.cuda.synchronize()
+    assert R.STATS["row_scans_carried"] == before + 2
+    for m, (ref, ref_total), t in ((ma, refs[0], ta), (mb, refs[1], tb)):
+        for a, b in zip(_grads(m), ref):
+            assert torch.equal(a, b)
+        assert torch.equal(t.detach(), ref_total)
+    assert ma.raster_state is not mb.raster_state
+
+
+def test_objective_backward_after_the_rasterizer_backward(gpu_device, monkeypatch):
+    """The order the round-3 advisor found: forward A, forward B, objective(A) takes a job, B is back-propagated through
+    ANOTHER loss (its backward scans itself and gives its buffers back), the next forward re-uses them, and only then the
+    objective's backward runs.  No half of a scan may be launched into recycled buffers: A's gradients equal the solo run."""
+    from gaussmart_amd import rasterizer as R
+    from gaussmart_amd.gaussian_renderer import render
+    from gaussmart_amd.trainer import training_losses
+    dev = gpu_device
+    fresh, cam, gt, pipe, opt, bg = _scene(dev)
+    ref, ref_total = _reference(dev, fresh, cam, gt, pipe, opt, bg, monkeypatch)
+    ma, mb = fresh(), fresh()
+    pa = render(cam, ma, pipe, bg, surface_maps=False)
+    pb = render(cam, mb, pipe, bg, surface_maps=False)
+    ta, _ = training_losses(pa, gt, opt, 10000, cam, pipe)
+    jb = pb["render"].grad_fn.row_scan_job
+    (pb["render"] - gt).abs().mean().backward()        # B: not through the fused objective
+    assert jb._dead and not jb._taken
+    with torch.no_grad():                              # re-uses the pooled buffers B's backward released
+        render(cam, mb, pipe, bg, surface_maps=False)
+    ta.backward()
+    torch.cuda.synchronize()
+    for a, b in zip(_grads(ma), ref):
+        assert torch.equal(a, b)
+    assert torch.equal(ta.detach(), ref_total)
+
+
+def test_rasterizer_backward_before_the_objective_backward(gpu_device, monkeypatch):
+    """One forward, two losses: the objective takes the job (first half enqueued), then the SECOND loss is back-propagated
+    first (retain_graph) -- the rasterizer's backward finds the job half done, scans itself and retires it -- then the
+    objective's backward runs and must NOT enqueue the second half; the rasterizer's second backward scans again.
+    Sum of both gradient sets == the gradient of the summed loss of the plain path (same kernels, same order of adds)."""
+    from gaussmart_amd import rasterizer as R
+    from gaussmart_amd.gaussian_renderer import render
+    from gaussmart_amd.trainer import training_losses
+    dev = gpu_device
+    fresh, cam, gt, pipe, opt, bg = _scene(dev)
+    monkeypatch.setattr(R, "KEEP_BUFFERS_AFTER_BACKWARD", True)
+    side = lambda pkg: (pkg["render"] - gt).square().mean()
+    ref_obj, _ = _reference(dev, fresh, cam, gt, pipe, opt, bg, monkeypatch)
+    m = fresh()
+    pkg = render(cam, m, pipe, bg, surface_maps=False)
+    job = pkg["render"].grad_fn.row_scan_job
+    total, _ = training_losses(pkg, gt, opt, 10000, cam, pipe)
+    assert job._taken and job.stage == 1
+    before = R.STATS["row_scans_carried"]
+    side(pkg).backward(retain_graph=True)
+    assert job._dead
+    g_side = _grads(m)
+    for p in m.parameters():
+        p.grad = None
+    total.backward()
+    torch.cuda.synchronize()
+    assert R.STATS["row_scans_carried"] == before     # neither backward found a finished scan, both scanned themselves
+    for a, b in zip(_grads(m), ref_obj):
+        assert torch.equal(a, b)
+    assert all(torch.isfinite(g).all() for g in g_side)
+
+
+def test_backward_twice_after_the_job_was_consumed(gpu_device, monkeypatch):
+    """retain_graph: the first backward consumes the finished scan, the second one (job dead, buffers kept) scans itself:
+    identical gradients."""
+    from gaussmart_amd import rasterizer as R
+    from gaussmart_amd.gaussian_renderer import render
+    from gaussmart_amd.trainer import training_losses
+    dev = gpu_device
+    fresh, cam, gt, pipe, opt, bg = _scene(dev)
+    monkeypatch.setattr(R, "KEEP_BUFFERS_AFTER_BACKWARD", True)
+    m = fresh()
+    pkg = render(cam, m, pipe, bg, surface_maps=False)
+    total, _ = training_losses(pkg, gt, opt, 10000, cam, pipe)
+    before = R.STATS["row_scans_carried"]
+    total.backward(retain_graph=True)
+    first = _grads(m)
+    for p in m.parameters():
+        p.grad = None
+    total.backward()
+    torch.cuda.synchronize()
+    assert R.STATS["row_scans_carried"] == before + 1
+    for a, b in zip(_grads(m), first):
+        assert torch.equal(a, b)
+
+
+def test_deferred_objective_value_reads_nan_until_the_backward(gpu_device):
+    """training_objective(defer_value=True): the five scalars are written by a workgroup of the backward; before it -- or
+    without it -- they must be visibly invalid, not uninitialised memory."""
+    from gaussmart_amd.fused_objective import training_objective
+    from gaussmart_amd.gaussian_renderer import render
+    dev = gpu_device
+    fresh, cam, gt, pipe, opt, bg = _scene(dev, n=5000, w=160, h=120)
+    m = fresh()
+    pkg = render(cam, m, pipe, bg, surface_maps=False)
+    total, parts = training_objective(pkg["render"], pkg["allmap"], gt, cam, 0.2, 0.05, 0.0, 0.0, defer_value=True)
+    assert math.isnan(float(total)) and bool(torch.isnan(parts).all())
+    total.backward()
+    torch.cuda.synchronize()
+    assert math.isfinite(float(total)) and bool(torch.isfinite(parts).all())
+    m2 = fresh()
+    pkg2 = render(cam, m2, pipe, bg, surface_maps=False)
+    total2, _ = training_objective(pkg2["render"], pkg2["allmap"], gt, cam, 0.2, 0.05, 0.0, 0.0, defer_value=False)
+    assert torch.equal(total2.detach(), total.detach())
+
+
+def test_factored_gradient_needs_a_state():
+    from gaussmart_amd import rasterizer as R
+    with pytest.raises(ValueError):
+        R.rasterize_gaussians_raw(torch.zeros(1, 3), None, None, None, None, None, None, None, factored_sh_grad=True)
