@@ -288,6 +288,15 @@ def main():
     ap.add_argument("--cpu-gaussians", type=int, default=250_000)
     ap.add_argument("--cpu-full", action="store_true", help="CPU baseline on the whole frame, un-sampled (~2 min)")
     ap.add_argument("--forward-frames", type=int, default=50, help="inference frames (no_grad render) timed after the run")
+    ap.add_argument("--mode", choices=("fused", "dropin"), default="fused",
+                    help="fused (default, the headline): the build's own trainer -- raw-parameter operator, fused objective, "
+                         "factored SH Adam.  dropin: what INTEGRATION.md section 1 delivers under the reference's own loop -- "
+                         "the reference-signature operator from diff_surfel_rasterization with torch activations "
+                         "(gaussian_renderer/__init__.py:55-106), the torch post-processing of render(), torch L1 + SSIM "
+                         "(utils/loss_utils.py), torch.optim.Adam and one .item() per step (train.py:112-152,214)")
+    ap.add_argument("--eval-flags", action="store_true",
+                    help="the flags the reference's evaluation scripts train with (scripts/dtu_eval.py:45: "
+                         "--lambda_normal 0 --lambda_dist 0): no gradient reaches the surface channels of allmap")
     ap.add_argument("--channels", type=int, default=3,
                     help="wide per-pixel payload (BASELINE.json config 5): time the operator's forward + backward with "
                          "colors_precomp [N,C], C = 4..64 (multiple of 4), on the chosen preset instead of the training step")
@@ -349,6 +358,14 @@ def main():
         pipe.fused_activations = False
     if os.environ.get("GSR_BENCH_UNFACTORED"):             # A/B aid: explicit SH gradient tensors (58 floats per Gaussian)
         pipe.factored_sh_grad = False
+    if args.eval_flags:                                    # scripts/dtu_eval.py:45
+        opt.lambda_normal, opt.lambda_dist = 0.0, 0.0
+    dropin = args.mode == "dropin"
+    if dropin:
+        if world > 1:
+            raise SystemExit("--mode dropin is the reference's single-GPU loop (it has no distributed code)")
+        pipe.fused_activations = False
+        pipe.factored_sh_grad = False
 
     target = GaussianModel(3, device=dev)
     target.create_from_params(perturb(params))
@@ -357,10 +374,14 @@ def main():
     del target
     model = GaussianModel(3, device=dev)
     model.create_from_params(params)
+    if dropin:
+        model.use_fused_adam = False       # torch.optim.Adam over the six parameter groups (scene/gaussian_model.py:282-295)
     model.training_setup(opt)
     force_dp = bool(os.environ.get("GSR_BENCH_FORCE_DP")) and dist.is_initialized()   # rehearsal on one GPU
     vp = ViewParallel(model, force=force_dp) if (world > 1 or force_dp) else None
-    if vp is None and os.environ.get("GSR_BENCH_LOCAL_OVERLAP", "1") != "0":
+    if dropin:
+        vp = None
+    elif vp is None and os.environ.get("GSR_BENCH_LOCAL_OVERLAP", "1") != "0":
         # N = 1: the same step pipeline as N > 1, minus the exchange -- the HBM-bound SH update (and the next forward's SH
         # colour pass behind it) run on a side stream beside the next forward's latency-bound depth sort / binning.  Same
         # kernels, same arithmetic, bit-identical parameters (tests/test_gpu_view_parallel.py); everything is joined by
@@ -381,6 +402,29 @@ def main():
     next_cam = cam if os.environ.get("GSR_BENCH_COLOR_CACHE", "1") != "0" else None
     def step(i):
         training_step(model, cam, gt, opt, pipe, bg, base_iter + i, view_parallel=vp, next_cam=next_cam)
+
+    if dropin:
+        # One iteration of the reference's loop (train.py:93-216) around the drop-in operator: render() with torch
+        # activations and the torch post-processing (expected depth, depth_to_normal, ...), torch L1 + SSIM, the two
+        # regularizers, backward, one .item() (the reference reads four for its progress bar), torch Adam.
+        from gaussmart_amd.losses import l1_loss, ssim
+        ema = [0.0]
+
+        def step(i):        # noqa: F811
+            it = base_iter + i
+            model.update_learning_rate(it)
+            pkg = render(cam, model, pipe, bg)
+            image = pkg["render"]
+            Ll1 = l1_loss(image, gt)
+            loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim(image, gt))
+            lambda_normal = opt.lambda_normal if it > 7000 else 0.0
+            lambda_dist = opt.lambda_dist if it > 3000 else 0.0
+            normal_error = (1 - (pkg["rend_normal"] * pkg["surf_normal"]).sum(dim=0))[None]
+            total = loss + lambda_dist * pkg["rend_dist"].mean() + lambda_normal * normal_error.mean()
+            total.backward()
+            ema[0] = 0.4 * loss.item() + 0.6 * ema[0]
+            model.optimizer.step()
+            model.optimizer.zero_grad(set_to_none=True)
 
     # Python's cyclic garbage collector runs when allocation counts cross a threshold, i.e. at arbitrary steps, and a full
     # collection stalls the host for a millisecond or more -- in a 20-step timed region that is several per cent of noise
@@ -499,6 +543,8 @@ def main():
             training_step(model, cam, gt, opt, pipe, bg, base_iter + args.warmup + args.steps, step_optimizer=False)
             b.record()
             model.optimizer.zero_grad(set_to_none=True)
+            if hasattr(model.optimizer, "take_pending_sh"):
+                model.optimizer.take_pending_sh()
         torch.cuda.synchronize()
         ref_iter_ms = sorted(a.elapsed_time(b) for a, b in ev)[n_ref // 2]
         if args.forward_frames > 0:
@@ -550,7 +596,15 @@ def main():
                        "tile_list_mean": round(D / tiles, 1), "entries_walked_per_pixel_mean": round(float(nc.mean()), 1),
                        "entries_walked_per_pixel_max": int(nc.max()),
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",
-                       "step_pipeline": "SH Adam update + next colour pass on a side stream beside the next forward's binning"
+                       "mode": args.mode + (" (reference-signature operator under a reference-shaped loop: torch activations, "
+                                            "torch post-processing + L1 + SSIM, torch.optim.Adam, one .item() per step)"
+                                            if dropin else " (raw-parameter operator, fused objective, factored SH Adam)"),
+                       "loss": "L1 + SSIM only (--eval-flags: lambda_normal 0, lambda_dist 0, scripts/dtu_eval.py:45)"
+                               if args.eval_flags else "L1 + SSIM + normal consistency (lambda_normal 0.05, lambda_dist 0)",
+                       "step_pipeline": ("SH Adam update + next colour pass on a side stream beside the next forward's binning; "
+                                         "every step renders the SAME view, so the optimiser step always leaves the next "
+                                         "forward's SH colours (colour cache hit on every step)" if next_cam is not None else
+                                         "SH Adam update on a side stream beside the next forward's binning")
                                         if (vp is not None and (vp.overlap_local or world > 1 or force_dp)) else "serial"},
             "ms_per_step_median": median_ms,
             "ms_per_step_chunks": [round(x, 4) for x in step_ms_chrono],      # 10 chunks of consecutive steps, in order

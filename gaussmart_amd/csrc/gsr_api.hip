@@ -113,6 +113,10 @@ static int validate(const GsrView* v, const GsrGaussians* g) {
             return GSR_E_INVALID;
         }
     }
+    if ((v->flags & (uint32_t)GSR_FLAG_COLOR_ONLY) && (v->channels != 3 || (v->flags & (uint32_t)GSR_FLAG_FORWARD_ONLY))) {
+        gsr_set_error("GSR_FLAG_COLOR_ONLY is for the 3-channel training forward (not with GSR_FLAG_FORWARD_ONLY)");
+        return GSR_E_INVALID;
+    }
     const bool color_cached = (v->flags & (uint32_t)GSR_FLAG_COLOR_CACHED) != 0;
     if (color_cached) {   // SH coefficients AND their cached colour for this view (gsr_adam_sh_factored_next)
         if (!g->shs || !g->colors_precomp || v->channels != 3 || v->sh_coeffs > 16) {
@@ -413,6 +417,11 @@ extern "C" int32_t gsr_backward_with_job(const GsrView* view, const GsrGaussians
         gsr_set_error("gsr_backward called for a GSR_FLAG_FORWARD_ONLY forward: nothing was kept for it");
         return GSR_E_INVALID;
     }
+    if ((view->flags & (uint32_t)GSR_FLAG_COLOR_ONLY) && !(view->flags & (uint32_t)GSR_FLAG_NO_SURFACE_GRAD)) {
+        gsr_set_error("gsr_backward of a GSR_FLAG_COLOR_ONLY forward needs GSR_FLAG_NO_SURFACE_GRAD: the forward kept no "
+                      "state for gradients of allmap");
+        return GSR_E_INVALID;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     const int N = g->count, W = view->width, H = view->height;
     const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
@@ -480,7 +489,7 @@ extern "C" int32_t gsr_backward_with_job(const GsrView* view, const GsrGaussians
                                    at<float>(geom, GL.splat), touch, slot_off, at<float>(image, IL.final_T),
                                    at<uint32_t>(image, IL.n_contrib), dL_dcolor, dL_dallmap, grad_rows, grad_xy,
                                    N, at<uint32_t>(geom, GL.offs), row_begin,
-                                   wide ? g->colors_precomp : nullptr, at<uint32_t>(binning, BL.point_list), feat_rows, s);
+                                   wide ? g->colors_precomp : nullptr, at<uint32_t>(binning, BL.point_list), feat_rows, n_rows, s);
         if (rc != GSR_OK) return rc;
     }
     GsrGrads o = *grads;

@@ -171,7 +171,7 @@ int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32
                           const float* splat, const uint32_t* touch, const uint32_t* slot_off, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
                           float* grad_xy, int N, const uint32_t* offs, uint32_t* row_begin, const float* feat,
-                          const uint32_t* point_list, float* feat_rows, hipStream_t s);
+                          const uint32_t* point_list, float* feat_rows, size_t max_rows, hipStream_t s);
 int gsr_launch_reduce_feat_rows(int N, int C, const uint32_t* order, const uint32_t* row_begin,
                                 const float* feat_rows, float* dL_dcolors, hipStream_t s);
 int gsr_launch_reduce_rows(int N, const uint32_t* order, const uint32_t* row_begin,

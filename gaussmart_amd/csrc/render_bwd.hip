@@ -49,15 +49,26 @@ extern "C" int gsr_probe_read_stamps_bwd(void* dst, size_t bytes) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rb_stamps), bytes < sizeof(g_rb_stamps) ? bytes : sizeof(g_rb_stamps)) == hipSuccess ? 0 : -1;
 }
 #endif
-template <int PROBE = 0>
-__global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(RenderBwdParams p) {
+// NOSURF (round 4; GSR_FLAG_NO_SURFACE_GRAD): the caller promises that dL/dallmap is identically zero -- the reference's own
+// evaluation flags (scripts/dtu_eval.py:45: --lambda_normal 0 --lambda_dist 0) and the first 7,000 iterations of EVERY run
+// (train.py:132-133: lambda_normal from 7,000, lambda_dist from 3,000 and 0 by default).  Then no gradient reaches depth,
+// alpha, normal, median depth or distortion: dL/dz = 0 and dL/dn = 0 identically, the per-pixel state loses five loads and
+// ten registers, and the staged record needs neither the normal nor the cull rect: 16 floats instead of 20, FOUR per-lane
+// ds_read_b128 per iteration instead of five (the fifth was worth 4 % of the kernel: DESIGN.md section 4, probe 8).  The
+// entry's first gradient row and its touch nibble share the sixteenth word: row + popcount of the touch bits of the quads
+// before this one (28 bits; the launcher falls back to the general kernel beyond 2^28 rows) | this quad's nibble << 28.
+// Same arithmetic in the same order for everything that is not multiplied by one of those zeros, so the gradients equal the
+// general kernel's fed with a zero dL/dallmap bit for bit (tests/test_gpu_rasterizer.py).
+template <int PROBE = 0, bool NOSURF = false>
+__global__ void __launch_bounds__(RB_BLOCK, NOSURF ? 8 : RB_MIN_WAVES) render_bwd_kernel(RenderBwdParams p) {
 #ifdef GSR_DEV_PROBES
     unsigned long long stamp_t0 = 0, stamp_c0 = 0;
     if (PROBE == 7) { stamp_t0 = __builtin_amdgcn_s_memrealtime(); stamp_c0 = __builtin_amdgcn_s_memtime(); }
 #endif
     __shared__ float s_probe_pad[PROBE == 6 ? 5120 : 1];
     if (PROBE == 6 && p.W < 0) s_probe_pad[threadIdx.x] = 1.f;
-    __shared__ float4 s_rec_all[RB_WAVES][64 * 5];
+    constexpr int RS = NOSURF ? 4 : 5;          // float4 parts of a staged record
+    __shared__ float4 s_rec_all[RB_WAVES][64 * RS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -72,6 +83,7 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
     const int qx0 = tile_x * GSR_TILE + (wave & 1) * 8, qy0 = tile_y * GSR_TILE + (wave >> 1) * 8;
     const int grp = lane >> 4, l16 = lane & 15;   // DPP row = 4x4 pixel block, same mapping as render_fwd
     const uint32_t below_mask = ((1u << (8 * wave + grp)) - 1u) & 0x0F0F0F0Fu;   // touch bits of the blocks before mine
+    const uint32_t quads_below_mask = ((1u << (8 * wave)) - 1u) & 0x0F0F0F0Fu;   // ... of the quads before mine (NOSURF)
     const uint32_t pick_shift = (uint32_t)grp * 16u;   // where this row's pick sits in the packed 64-bit scalar
     const int pxi = qx0 + (grp & 1) * 4 + (l16 & 3), pyi = qy0 + (grp >> 1) * 4 + (l16 >> 2);
     const bool inside = pxi < p.W && pyi < p.H;
@@ -97,16 +109,16 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
 
     // per-pixel state saved by the forward
     const float T_final = inside ? p.final_T[pix_id] : 0.f;
-    const float final_D = inside ? p.final_T[pix_id + HW] : 0.f;       // sum m w
-    const float final_D2 = inside ? p.final_T[pix_id + 2 * HW] : 0.f;  // sum m^2 w
+    const float final_D = (!NOSURF && inside) ? p.final_T[pix_id + HW] : 0.f;       // sum m w
+    const float final_D2 = (!NOSURF && inside) ? p.final_T[pix_id + 2 * HW] : 0.f;  // sum m^2 w
     const float final_A = 1.0f - T_final;
-    const int median_contributor = inside ? (int)p.n_contrib[pix_id + HW] : 0;
+    const int median_contributor = (!NOSURF && inside) ? (int)p.n_contrib[pix_id + HW] : 0;
 
     float dL_dpix0 = 0.f, dL_dpix1 = 0.f, dL_dpix2 = 0.f;
     float dL_ddepth = 0.f, dL_daccum = 0.f, dL_dreg = 0.f, dL_dmedian = 0.f;
     float dL_dn0 = 0.f, dL_dn1 = 0.f, dL_dn2 = 0.f;
-    if (inside) {
-        dL_dpix0 = p.dL_dcolor[pix_id]; dL_dpix1 = p.dL_dcolor[pix_id + HW]; dL_dpix2 = p.dL_dcolor[pix_id + 2 * HW];
+    if (inside) { dL_dpix0 = p.dL_dcolor[pix_id]; dL_dpix1 = p.dL_dcolor[pix_id + HW]; dL_dpix2 = p.dL_dcolor[pix_id + 2 * HW]; }
+    if (!NOSURF && inside) {
         dL_ddepth = p.dL_dallmap[pix_id + 0 * HW];
         dL_daccum = p.dL_dallmap[pix_id + 1 * HW];
         dL_dn0 = p.dL_dallmap[pix_id + 2 * HW];
@@ -117,8 +129,8 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
     }
     const float bg_dot_dpixel = p.bg[0] * dL_dpix0 + p.bg[1] * dL_dpix1 + p.bg[2] * dL_dpix2;
 
-    const bool quad_has_dist = __any(dL_dreg != 0.f), quad_has_median = __any(dL_dmedian != 0.f);   // wave-uniform
-    const bool quad_has_surf = __any(dL_ddepth != 0.f || dL_daccum != 0.f || dL_dn0 != 0.f || dL_dn1 != 0.f || dL_dn2 != 0.f);
+    const bool quad_has_dist = !NOSURF && __any(dL_dreg != 0.f), quad_has_median = !NOSURF && __any(dL_dmedian != 0.f);   // wave-uniform
+    const bool quad_has_surf = !NOSURF && __any(dL_ddepth != 0.f || dL_daccum != 0.f || dL_dn0 != 0.f || dL_dn1 != 0.f || dL_dn2 != 0.f);
 
     // running state of the back-to-front recursion
     float T = T_final;
@@ -155,8 +167,16 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
         // the record's two cull-rect words mean nothing to the backward: the staged copy carries the entry's first row
         // and its touch word there instead, so a block that picks entry j reads them with the record (they used to come
         // through two ds_bpermute per iteration)
-        s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_rec[lane * 5 + 3] = pf3;
-        s_rec[lane * 5 + 4] = make_float4(pf4.x, pf4.y, __uint_as_float(slot_of_lane), __uint_as_float(touch_of_lane));
+        if (NOSURF) {   // [Tu Tv.x | Tv.yz Tw.xy | Tw.z xy opacity | rgb (first row up to this quad | this quad's nibble << 28)]
+            const uint32_t packed = (slot_of_lane + (uint32_t)__popc(touch_of_lane & quads_below_mask)) |
+                                    (((touch_of_lane >> (8 * wave)) & 0xFu) << 28);
+            s_rec[lane * RS] = pf0; s_rec[lane * RS + 1] = pf1;
+            s_rec[lane * RS + 2] = make_float4(pf2.x, pf2.y, pf2.z, pf3.z);
+            s_rec[lane * RS + 3] = make_float4(pf3.w, pf4.x, pf4.y, __uint_as_float(packed));
+        } else {
+            s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_rec[lane * 5 + 3] = pf3;
+            s_rec[lane * 5 + 4] = make_float4(pf4.x, pf4.y, __uint_as_float(slot_of_lane), __uint_as_float(touch_of_lane));
+        }
         {   // prefetch the next (shallower) batch
             const int hi2 = lo, lo2 = max(0, hi2 - 64), cnt = hi2 - lo2;
             pf_slot = lane < cnt ? p.slot_off[rows_nxt] : 0u;
@@ -191,8 +211,9 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
             const bool has = jrev >= 0;
             const int j = (63 - jrev) & 63;
             const int cidx = lo + j;                            // 0-based position in the tile list
-            const float4 a0 = s_rec[j * 5 + 0], a1 = PROBE == 8 ? a0 : s_rec[j * 5 + 1], a2 = s_rec[j * 5 + 2];
-            const float4 a3 = s_rec[j * 5 + 3];
+            const float4 a0 = s_rec[j * RS + 0], a1 = PROBE == 8 ? a0 : s_rec[j * RS + 1], a2 = s_rec[j * RS + 2];
+            const float4 a3 = s_rec[j * RS + 3];     // general: [n.y n.z opacity r]; NOSURF: [r g b packed row | nibble]
+            const float opa = NOSURF ? a2.w : a3.z;
             // Branch-free: EVERY lane runs the gradient math (masked-off lanes would cost the same issue slots),
             // and a lane that does not blend this splat gets alpha = G = 0 and harmless finite geometry, which
             // makes all 18 of its partial derivatives exact zeros and leaves its recursion state untouched
@@ -206,14 +227,22 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
                 for (int q = 0; q < 8; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(probe_s) : : "scc");
             }
             GsrPair pr;
-            const bool ok = gsr_pair_eval(pxf, pyf, a0, a1, a2, a3.z, pr);
+            const bool ok = gsr_pair_eval(pxf, pyf, a0, a1, a2, opa, pr);
             const bool active = has && cidx < last_contributor && ok;
             float gT[9];
             float gxy0, gxy1, gn0, gn1, gn2, gopa, gc0, gc1, gc2;
             uint32_t rec_slot, rec_touch;   // first gradient row and touch word of this row's entry (staged with the record)
             {
-                const float4 a4 = s_rec[j * 5 + 4];
-                rec_slot = __float_as_uint(a4.z); rec_touch = __float_as_uint(a4.w);
+                float4 a4;
+                if (NOSURF) {
+                    const uint32_t packed = __float_as_uint(a3.w);
+                    rec_slot = packed & 0x0FFFFFFFu;               // (already counts the quads before this one)
+                    rec_touch = (packed >> 28) << (8 * wave);      // this quad's nibble, where below_mask looks for it
+                    a4 = make_float4(a3.y, a3.z, 0.f, 0.f);
+                } else {
+                    a4 = s_rec[j * 5 + 4];
+                    rec_slot = __float_as_uint(a4.z); rec_touch = __float_as_uint(a4.w);
+                }
                 const float alpha = active ? pr.alpha : 0.f, G = active ? pr.G : 0.f, c_d = active ? pr.depth : 1.f;
                 const float sx = active ? pr.sx : 0.f, sy = active ? pr.sy : 0.f, inv_pz = active ? pr.inv_pz : 0.f;
                 const float one_m_alpha = 1.0f - alpha;
@@ -223,8 +252,8 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
 
                 // colour, expected depth, alpha and normal share one suffix recursion:
                 //   q_i = c_i . dL/dC + z_i dL/dD + 1 dL/dA + n_i . dL/dN
-                const float c0 = a3.w, c1 = a4.x, c2 = a4.y;
-                const float n0 = a2.w, n1 = a3.x, n2 = a3.y;
+                const float c0 = NOSURF ? a3.x : a3.w, c1 = a4.x, c2 = a4.y;
+                const float n0 = a2.w, n1 = a3.x, n2 = a3.y;    // (only read when quad_has_surf)
                 // (the surface channels -- depth, alpha, normal -- carry no gradient before the regularizers switch on)
                 float q = 0.f;
                 if (quad_has_surf) q = c_d * dL_ddepth + dL_daccum + n0 * dL_dn0 + n1 * dL_dn1 + n2 * dL_dn2;
@@ -239,7 +268,7 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
                 // median depth and distortion: skipped (wave-uniformly) when the whole quad receives no gradient on that
                 // channel -- the reference's defaults (depth_ratio = 0, lambda_dist = 0) make both identically zero, and
                 // every term below is a multiple of it
-                float dL_dz = w * dL_ddepth;
+                float dL_dz = NOSURF ? 0.f : w * dL_ddepth;
                 if (quad_has_median && active && cidx == median_contributor - 1) dL_dz += dL_dmedian;
                 if (quad_has_dist) {
                     float dmd_dd;
@@ -257,13 +286,13 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
 
                 // alpha = min(0.99, opa * G)
                 const float dL_daraw = (clamp_pass || pr.araw <= GSR_ALPHA_MAX) ? dL_dalpha : 0.f;
-                const float dL_dG = a3.z * dL_daraw;
+                const float dL_dG = opa * dL_daraw;
                 gopa = G * dL_daraw;
 
                 const float Twx = a1.z, Twy = a1.w;
                 if (pr.use3d) {
-                    const float dL_dsx = dL_dG * (-G * sx) + dL_dz * Twx;
-                    const float dL_dsy = dL_dG * (-G * sy) + dL_dz * Twy;
+                    const float dL_dsx = NOSURF ? dL_dG * (-G * sx) : dL_dG * (-G * sx) + dL_dz * Twx;
+                    const float dL_dsy = NOSURF ? dL_dG * (-G * sy) : dL_dG * (-G * sy) + dL_dz * Twy;
                     const float dpx = dL_dsx * inv_pz, dpy = dL_dsy * inv_pz;
                     const float dpz = -(dpx * sx + dpy * sy);
                     // dL/dTu = -dL/dk = dL/dp x l ;  dL/dTv = -dL/dl = k x dL/dp
@@ -271,16 +300,22 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
                     const float vx = pr.ky * dpz - pr.kz * dpy, vy = pr.kz * dpx - pr.kx * dpz, vz = pr.kx * dpy - pr.ky * dpx;
                     gT[0] = ux; gT[1] = uy; gT[2] = uz;
                     gT[3] = vx; gT[4] = vy; gT[5] = vz;
-                    gT[6] = dL_dz * sx - pxf * ux - pyf * vx;
-                    gT[7] = dL_dz * sy - pxf * uy - pyf * vy;
-                    gT[8] = dL_dz - pxf * uz - pyf * vz;
+                    if (NOSURF) {      // (the general form with dL_dz = +0: 0 * s - a - b == -a - b up to the sign of a zero)
+                        gT[6] = 0.f - pxf * ux - pyf * vx;
+                        gT[7] = 0.f - pxf * uy - pyf * vy;
+                        gT[8] = 0.f - pxf * uz - pyf * vz;
+                    } else {
+                        gT[6] = dL_dz * sx - pxf * ux - pyf * vx;
+                        gT[7] = dL_dz * sy - pxf * uy - pyf * vy;
+                        gT[8] = dL_dz - pxf * uz - pyf * vz;
+                    }
                     gxy0 = 0.f; gxy1 = 0.f;
                 } else {
                     gxy0 = dL_dG * (-G * GSR_FILTER_INV_SQUARE * pr.dx);
                     gxy1 = dL_dG * (-G * GSR_FILTER_INV_SQUARE * pr.dy);
                     gT[0] = 0.f; gT[1] = 0.f; gT[2] = 0.f; gT[3] = 0.f; gT[4] = 0.f; gT[5] = 0.f;
-                    gT[6] = filter_depth_quirk ? sx * dL_dz : 0.f;
-                    gT[7] = filter_depth_quirk ? sy * dL_dz : 0.f;
+                    gT[6] = (!NOSURF && filter_depth_quirk) ? sx * dL_dz : 0.f;
+                    gT[7] = (!NOSURF && filter_depth_quirk) ? sy * dL_dz : 0.f;
                     gT[8] = dL_dz;
                 }
             }
@@ -293,6 +328,7 @@ __global__ void __launch_bounds__(RB_BLOCK, RB_MIN_WAVES) render_bwd_kernel(Rend
                 const float xy = row_sum2(gxy0, gxy1, l16);
                 // every row whose to-do bit was set writes its slot (zeros if no pixel turned out active), so
                 // the reduction never reads a row that was not written
+                // (NOSURF: rec_slot already counts the quads before this one and rec_touch holds this quad's nibble only)
                 const size_t slot = (size_t)rec_slot + __popc(rec_touch & below_mask);
                 if (has) {
                     p.grad_rows[slot * RB_ROW + l16] = tot;                   // one aligned 64-byte store per row
@@ -397,7 +433,7 @@ int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32
                           const float* splat, const uint32_t* touch, const uint32_t* slot_off, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dcolor, const float* dL_dallmap, float* grad_rows,
                           float* grad_xy, int N, const uint32_t* offs, uint32_t* row_begin, const float* feat,
-                          const uint32_t* point_list, float* feat_rows, hipStream_t s) {
+                          const uint32_t* point_list, float* feat_rows, size_t max_rows, hipStream_t s) {
     RenderBwdParams p;
     p.W = v.width; p.H = v.height; p.gx = (v.width + GSR_TILE - 1) / GSR_TILE;
     const int gy = (v.height + GSR_TILE - 1) / GSR_TILE;
@@ -412,7 +448,11 @@ int gsr_launch_render_bwd(const GsrView& v, const uint32_t* ranges, const uint32
     GsrProfileScope prof(GSR_K_RENDER_BWD, s);
     p.n_tiles = p.gx * gy; p.per_xcd = (p.n_tiles + 7) / 8;
     const dim3 grid(8 * p.per_xcd), block(RB_BLOCK);
-    if (feat == nullptr) {
+    // no gradient on any allmap channel (the caller's promise) and row indices that fit 28 bits: the 4-part-record kernel
+    const bool nosurf = feat == nullptr && (v.flags & (uint32_t)GSR_FLAG_NO_SURFACE_GRAD) != 0 && max_rows < (size_t(1) << 28);
+    if (nosurf) {
+        hipLaunchKernelGGL((render_bwd_kernel<0, true>), grid, block, 0, s, p);
+    } else if (feat == nullptr) {
 #ifdef GSR_DEV_PROBES
         const char* e = getenv("GSR_K7_PROBE");   // re-read per launch
         switch (e ? atoi(e) : 0) {

@@ -9,6 +9,8 @@ The extra keyword `surface_maps=False` skips the five derived maps: the trainer'
 `allmap` to the fused regularizer kernels instead (gaussmart_amd/fused_regularizer.py).
 `factored_sh_grad=True` (only honoured on the raw-parameter path; set by trainer.training_step, which owns the
 optimiser step) makes the backward leave the colour gradient [N,3] instead of the two SH gradient tensors.
+`color_only=True` (raw-parameter path with `surface_maps=False`; set by trainer.training_step while no regularizer is
+active, i.e. before iteration 7,000 or with lambda_normal = lambda_dist = 0): "allmap" comes back as None.
 
 Device follows the model's tensors (the reference hard-codes "cuda").
 """
@@ -108,7 +110,7 @@ def _use_raw_path(pc, pipe, override_color, xyz):
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, *,
-           surface_maps=True, factored_sh_grad=False):
+           surface_maps=True, factored_sh_grad=False, color_only=False):
     xyz = pc.get_xyz
     device = xyz.device
     # the reference adds 0 and calls retain_grad() (gaussian_renderer/__init__.py:27-31); a leaf that requires
@@ -171,7 +173,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             cache = lookup(viewpoint_camera.camera_center, pc.active_sh_degree, pc._xyz, pc._features_dc, pc._features_rest)
         rendered_image, radii, allmap = rasterize_gaussians_raw(
             xyz, means2D, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation, raster_settings,
-            factored_sh_grad=factored and state is not None, color_cache=cache if state is not None else None, state=state)
+            factored_sh_grad=factored and state is not None, color_cache=cache if state is not None else None, state=state,
+            color_only=bool(color_only) and not surface_maps and torch.is_grad_enabled())
     else:
         rendered_image, radii, allmap = rasterizer(
             means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,

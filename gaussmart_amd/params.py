@@ -23,6 +23,9 @@ class PipelineParams:
     # not in the reference: the backward returns dL/drgb [N,3] and the Adam kernel of the SH tensors rebuilds
     # basis(dir) x dL/drgb itself (48 -> 3 gradient floats per Gaussian written, read and exchanged between GPUs)
     factored_sh_grad: bool = True
+    # not in the reference: while no regularizer is active the fused trainer asks the forward for the colour image alone
+    # (GSR_FLAG_COLOR_ONLY: allmap neither accumulated nor written; the reference computes it and multiplies it by zero)
+    color_only_when_unregularized: bool = True
 
 
 @dataclass

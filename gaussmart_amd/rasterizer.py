@@ -267,6 +267,8 @@ class RasterState:
 # the buffers went back to the pool (an objective whose backward runs later, or twice) is never launched.
 # GSR_ROW_SCAN_RIDE=0 switches the hand-over off.
 _ROW_SCAN_RIDE = __import__("os").environ.get("GSR_ROW_SCAN_RIDE", "1") != "0"
+# a backward that receives no gradient for allmap says so (GSR_FLAG_NO_SURFACE_GRAD); GSR_NO_SURFACE_FAST_PATH=0: A/B aid
+_NO_SURFACE_FAST_PATH = __import__("os").environ.get("GSR_NO_SURFACE_FAST_PATH", "1") != "0"
 
 
 def take_row_scan_job(image):
@@ -395,11 +397,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         H, W = int(rs.image_height), int(rs.image_width)
         grad_color = _f32c(grad_color, "grad_color", device) if grad_color is not None else \
             _zero_image(ctx.channels, H, W, device)
+        # nothing was differentiated through allmap (e.g. lambda_normal = lambda_dist = 0): the backward is told so
+        bwd_flags = ctx.flags | (_lib.GSR_FLAG_NO_SURFACE_GRAD if (grad_allmap is None and _NO_SURFACE_FAST_PATH) else 0)
         grad_allmap = _f32c(grad_allmap, "grad_allmap", device) if grad_allmap is not None else \
             _zero_image(7, H, W, device)
 
         with torch.cuda.device(device):
-            view, keep = _make_view(rs, sh.shape[1] if sh is not None else 0, ctx.flags, device, ctx.channels, ctx.view_keep)
+            view, keep = _make_view(rs, sh.shape[1] if sh is not None else 0, bwd_flags, device, ctx.channels, ctx.view_keep)
             g = _lib.GsrGaussians(N, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities),
                                   _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp), None)
             d_means3D = torch.empty_like(means3D)
@@ -434,7 +438,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings, flags,
-                color_cache=None, state=None):
+                color_cache=None, state=None, color_only=False):
         L = _lib.lib()
         device = xyz.device
         if device.type != "cuda":
@@ -449,6 +453,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             raise ValueError("features_dc must be [N,1,3] and features_rest [N,K-1,3]")
         M = 1 + f_rest.shape[1]
         flags = int(flags) | _lib.GSR_FLAG_RAW_PARAMS
+        if color_only:                    # the caller does not consume allmap (no regularizer active): not accumulated, not written
+            flags |= _lib.GSR_FLAG_COLOR_ONLY
         if color_cache is not None:       # the SH colour of this view was left by the optimiser step (FusedAdam.color_cache)
             if color_cache.numel() != 13 * N or color_cache.dtype != torch.float32 or color_cache.device != device:
                 raise ValueError("color_cache must be float32 [13 N] on the parameters' device")
@@ -498,7 +504,10 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                               alloc.buffers[_lib.GSR_BUF_GEOM], alloc.buffers[_lib.GSR_BUF_BINNING],
                               alloc.buffers[_lib.GSR_BUF_IMAGE])
         del keep
-        ctx.mark_non_differentiable(radii)
+        if color_only:
+            ctx.mark_non_differentiable(radii, allmap)       # (allmap was not written: rasterize_gaussians_raw hands back None)
+        else:
+            ctx.mark_non_differentiable(radii)
         return color, radii, allmap
 
     @staticmethod
@@ -506,15 +515,20 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         L = _lib.lib()
         _check_lease(ctx)
         xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, radii, geom, binning, image = ctx.saved_tensors
+        if ctx.flags & _lib.GSR_FLAG_COLOR_ONLY:
+            grad_allmap = None
         rs = ctx.raster_settings
         device = xyz.device
         N = xyz.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
         grad_color = _f32c(grad_color, "grad_color", device) if grad_color is not None else _zero_image(3, H, W, device)
+        # nothing was differentiated through allmap (the first 7,000 iterations, or lambda_normal = lambda_dist = 0)
+        bwd_flags = ctx.flags | (_lib.GSR_FLAG_NO_SURFACE_GRAD if (grad_allmap is None and (
+            _NO_SURFACE_FAST_PATH or ctx.flags & _lib.GSR_FLAG_COLOR_ONLY)) else 0)
         grad_allmap = _f32c(grad_allmap, "grad_allmap", device) if grad_allmap is not None else _zero_image(7, H, W, device)
         rest = f_rest if f_rest.shape[1] > 0 else None
         with torch.cuda.device(device):
-            view, keep = _make_view(rs, ctx.M, ctx.flags, device, 3, ctx.view_keep)
+            view, keep = _make_view(rs, ctx.M, bwd_flags, device, 3, ctx.view_keep)
             g = _lib.GsrGaussians(N, _ptr(xyz), _ptr(f_dc), _ptr(ctx.color_cache), _ptr(opacity_raw), _ptr(scaling_raw),
                                   _ptr(rotation_raw), None, _ptr(rest) if rest is not None else None)
             # ONE buffer for the six parameter gradients, [xyz | f_dc | opacity | scaling | rotation | f_rest]: the
@@ -569,7 +583,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         _finish_lease(ctx)
         if factored:
             ctx.state.color_grad = ColorGradRecord(flat, flat[:n_head], record, N, ctx.M, rs.sh_degree, xyz)
-        return d_xyz, d_2d, d_dc, d_rest, d_op, d_sc, d_rot, None, None, None, None
+        return d_xyz, d_2d, d_dc, d_rest, d_op, d_sc, d_rot, None, None, None, None, None
 
 
 def _wants_grad(*tensors):
@@ -604,13 +618,15 @@ def _forward_only(device, rs, flags, sh_coeffs, gaussians_args, N):
 
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
-                            raster_settings, flags=None, factored_sh_grad=False, color_cache=None, state=None):
+                            raster_settings, flags=None, factored_sh_grad=False, color_cache=None, state=None, color_only=False):
     """(color, radii, allmap) from the model's raw parameter tensors; activations fused in-kernel.
     `state`: the model's RasterState (hand-over slots with the optimiser step); None for a caller that has neither a
     pipelined update in flight nor a factored gradient to receive.
     `factored_sh_grad`: the backward leaves NO gradient on features_dc / features_rest; it leaves a ColorGradRecord in
     `state.color_grad` (RasterState.take_color_grad) for FusedAdam.step_sh_factored instead -- only for callers that own
-    the optimiser step, and only with a `state` to leave it in."""
+    the optimiser step, and only with a `state` to leave it in.
+    `color_only`: the caller consumes the colour image alone (a training step with no regularizer active): allmap comes back
+    as None -- the forward neither accumulates nor writes it (GSR_FLAG_COLOR_ONLY), the backward runs without its terms."""
     flags = DEFAULT_FLAGS if flags is None else flags
     if factored_sh_grad and state is None:
         raise ValueError("factored_sh_grad needs state=RasterState(): the backward leaves its colour-gradient record there")
@@ -628,9 +644,10 @@ def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_ra
                              xyz.shape[0])
     if factored_sh_grad:
         flags |= _lib.GSR_FLAG_FACTORED_SH_GRAD
-    return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
-                                        rotation_raw, raster_settings, flags, color_cache if factored_sh_grad else None,
-                                        state)
+    color, radii, allmap = _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
+                                                        rotation_raw, raster_settings, flags,
+                                                        color_cache if factored_sh_grad else None, state, bool(color_only))
+    return color, radii, (None if color_only else allmap)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,

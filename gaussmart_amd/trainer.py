@@ -12,6 +12,7 @@ import time
 import torch
 
 from .gaussian_renderer import render
+from . import rasterizer as _rasterizer
 from .fused_adam import FusedAdam
 from .fused_loss import photometric_loss as fused_photometric_loss
 from .fused_objective import training_objective
@@ -96,7 +97,12 @@ def training_step(gaussians, viewpoint_cam, gt_image, opt, pipe, background, ite
         gaussians.optimizer.next_view = (next_cam.camera_center, gaussians.active_sh_degree) \
             if (factored and next_cam is not None and getattr(pipe, "color_cache", True)) else None
     if factored:
-        render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=False, factored_sh_grad=True)
+        # while no regularizer is active (train.py:132-133: lambda_normal from iteration 7,000, lambda_dist from 3,000 and 0 by
+        # default; scripts/dtu_eval.py:45 trains with both at 0) nobody reads allmap: the forward does not build it
+        no_reg = not ((opt.lambda_normal > 0.0 and iteration > 7000) or (opt.lambda_dist > 0.0 and iteration > 3000))
+        render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=False, factored_sh_grad=True,
+                               color_only=no_reg and getattr(pipe, "color_only_when_unregularized", True)
+                               and _rasterizer._NO_SURFACE_FAST_PATH)      # (GSR_NO_SURFACE_FAST_PATH=0: A/B aid)
     else:
         render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=not on_device)
     # (the backward follows at once: the loss scalars are written by a workgroup of its first kernel, not by a launch of

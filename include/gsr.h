@@ -81,6 +81,16 @@ enum {
                                        pass would run (same position in the stream, same GSR_FLAG_DEFER_COLOR handling) and
                                        never reads the coefficients; gsr_backward (pass the same pointer and flag) takes
                                        d(rgb)/d(dir) from the cache.  The caller guarantees that the cache matches */
+    GSR_FLAG_COLOR_ONLY = 2048,     /* gsr_forward (RGB payload, not with GSR_FLAG_FORWARD_ONLY): the caller does not consume allmap -- a
+                                       trainer while no regularizer is active.  out->allmap is NOT written, the kept image state
+                                       holds T and the last contributor only; colour, radii and everything the backward walks are
+                                       those of the general forward bit for bit.  The backward of such a forward must carry
+                                       GSR_FLAG_NO_SURFACE_GRAD (gsr_backward rejects it otherwise) */
+    GSR_FLAG_NO_SURFACE_GRAD = 1024, /* gsr_backward only: the caller promises that dL_dallmap is identically zero (it must still
+                                       point at W*H*7 zeros) -- the reference's evaluation flags (scripts/dtu_eval.py:45:
+                                       --lambda_normal 0 --lambda_dist 0) and the first 7,000 iterations of every run
+                                       (train.py:132-133).  The compositing backward then runs without the surface terms on a
+                                       16-float staged record; same gradients as without the flag, bit for bit */
     GSR_FLAG_FACTORED_SH_GRAD = 32  /* gsr_backward with `shs`: the SH gradient of one view is the outer product
                                        basis_k(dir) x g_c of the 16 basis values of the view direction and the
                                        clamp-masked colour gradient g = dL/drgb (utils/sh_utils.py:57-112 is linear in

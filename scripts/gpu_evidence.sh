@@ -17,6 +17,11 @@ for f in ("bench_line","bench_line_20steps","prof_bench_line"):
     d=json.load(open(f"gpurun_out/{sys.argv[1]}_{f}.json"))
     print(f, round(d["value"],1), "it/s", round(d["ms_per_step"],3), "ms; median", round(d["ms_per_step_median"],4), "roofline", d["roofline"]["kernel"], round(d["roofline"]["frac"],4), "walked", round(d["roofline"]["walked"]["frac"],4), "cpu", d.get("cpu_baseline",{}).get("value"))
 PY
+# the lines next to the headline: drop-in mode, the reference's evaluation flags (with and without the colour-only forward
+# + 4-part-record backward), and where the drop-in step's time goes (rocprofv3 over 20 of its steps)
+bash scripts/bench_modes.sh ${tag}_modes > gpurun_out/${tag}_bench_modes.txt 2>&1; cat gpurun_out/${tag}_bench_modes.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_dropin -o p -- python3 bench.py --mode dropin --steps 20 --warmup 3 --no-cpu-baseline --forward-frames 0 > /dev/null 2> gpurun_out/${tag}_prof_dropin.err
+cp "$(find gpurun_out/${tag}_prof_dropin -name '*kernel_stats.csv' | head -1)" gpurun_out/${tag}_dropin_kernel_stats.csv; rm -rf gpurun_out/${tag}_prof_dropin
 bash scripts/bench_presets.sh $tag
 bash scripts/pmc_collect.sh $tag
 for c in 16 64; do python3 bench.py --channels $c --steps 20 --warmup 3 2>/dev/null >> gpurun_out/${tag}_wide_headline.jsonl; python3 bench.py --preset bicycle --channels $c --steps 10 --warmup 2 2>/dev/null >> gpurun_out/${tag}_wide_bicycle.jsonl; done

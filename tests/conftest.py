@@ -13,6 +13,49 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "oracle_cases(*keys): oracle-farm cases this test asks for (tests/oracle_farm.py)")
+
+
+def pytest_collection_finish(session):
+    """Start the CPU oracle of every selected GPU parity case in worker processes (tests/oracle_farm.py): they run beside
+    the GPU tests instead of inside them.  Only on a box with a device -- elsewhere those tests skip."""
+    try:
+        from oracle_farm import FARM
+    except Exception:
+        return
+    keys = []
+    for item in session.items:
+        if item.get_closest_marker("gpu") is None:
+            continue
+        cs = getattr(item, "callspec", None)
+        if cs is not None:
+            keys += [v for v in cs.params.values() if isinstance(v, str) and v in FARM.specs]
+        m = item.get_closest_marker("oracle_cases")
+        if m is not None:
+            keys += [k for k in m.args if k in FARM.specs]
+        fn = getattr(item, "function", None)
+        keys += [k for k in getattr(fn, "oracle_keys", ()) if k in FARM.specs]
+    keys = list(dict.fromkeys(keys))
+    if keys and torch.cuda.device_count() > 0:
+        n = FARM.start(keys)
+        print(f"\n[oracle farm] {len(keys)} oracle cases on {n} worker processes", flush=True)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    try:
+        from oracle_farm import FARM, REPORT, format_report
+    except Exception:
+        return
+    FARM.shutdown()
+    if REPORT:
+        text = format_report()
+        out = os.environ.get("GSR_BARS_REPORT")
+        if out:
+            os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+            with open(out, "w") as f:
+                f.write(text + "\n")
+        print("\n[gradient bars] measured figures per case and tensor (HIP vs fp64 oracle | fp32 oracle vs fp64 | bar usage)")
+        print(text)
 
 
 def oracle_settings(cam, deg=3, dtype=torch.float32, bg=(0.0, 0.0, 0.0), scale_modifier=1.0):

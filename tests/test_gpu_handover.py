@@ -204,10 +204,10 @@ def test_deferred_objective_value_reads_nan_until_the_backward(gpu_device):
     m = fresh()
     pkg = render(cam, m, pipe, bg, surface_maps=False)
     total, parts = training_objective(pkg["render"], pkg["allmap"], gt, cam, 0.2, 0.05, 0.0, 0.0, defer_value=True)
-    assert math.isnan(float(total)) and bool(torch.isnan(parts).all())
+    assert math.isnan(float(total.detach())) and bool(torch.isnan(parts).all())
     total.backward()
     torch.cuda.synchronize()
-    assert math.isfinite(float(total)) and bool(torch.isfinite(parts).all())
+    assert math.isfinite(float(total.detach())) and bool(torch.isfinite(parts).all())
     m2 = fresh()
     pkg2 = render(cam, m2, pipe, bg, surface_maps=False)
     total2, _ = training_objective(pkg2["render"], pkg2["allmap"], gt, cam, 0.2, 0.05, 0.0, 0.0, defer_value=False)

@@ -205,3 +205,45 @@ def test_row_scan_carried_by_the_objective_kernels(gpu_device, monkeypatch):
     assert len(grads[0]) == len(grads[1]) > 4
     for a, b in zip(grads[0], grads[1]):
         assert torch.equal(a, b)
+
+
+def test_reference_schedule_reduced_crosses_reset_and_sh_steps(gpu_device, monkeypatch):
+    """The reference's schedule (train.py:90-216 through trainer.train(), OptimizationParams defaults) at reduced size:
+    3,500 iterations from iteration 0 on a 400x300 scene, started SfM-like from every fourth Gaussian of the (perturbed)
+    target at SH degree 0.  The run crosses three SH-degree steps (1,000 / 2,000 / 3,000) with the factored SH Adam, thirty
+    densify / prune rounds, the opacity reset at 3,000 and the 20-px size threshold after it; the model more than doubles,
+    so the grow-only workspace has to re-grow.  Asserts: every parameter and Adam moment finite at every log point, PSNR
+    rising, the workspace re-grown, and a bit-identical repeat.  (The 30,000-iteration runs at the scan24-like and
+    bicycle-like shapes are scripts/full_schedule_train.py; their records are under profiles/.)"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import full_schedule_train as FS
+    from gaussmart_amd import rasterizer as R
+    from gaussmart_amd.gaussian_model import GaussianModel
+    resets = []
+    orig_reset = GaussianModel.reset_opacity
+    monkeypatch.setattr(GaussianModel, "reset_opacity", lambda self: (resets.append(self.get_xyz.shape[0]), orig_reset(self))[1])
+    runs = []
+    for rep in range(2):
+        torch.manual_seed(1234)                      # densify_and_split samples from the device's default generator
+        R.release_workspace()                        # start from an empty pool: earlier tests left larger buffers in it
+        created0 = R.STATS["pool_buffers_created"]
+        models = []
+        s = FS.run("small", 3500, views=8, log_every=500, seed=1, extent=5.0, schedule_iterations=30000, quiet=True,
+                   start_fraction=0.25, model_out=models)
+        runs.append((s, [p.detach().clone() for p in models[0].parameters()], R.STATS["pool_buffers_created"] - created0))
+        del models
+    s, params, created = runs[0]
+    assert s["all_finite_at_every_log_point"] and all(torch.isfinite(p).all() for p in params)
+    assert s["final_sh_degree"] == 3                                   # three SH-degree steps
+    assert len(resets) == 2 and s["iterations"] > 3000                 # one opacity reset per run
+    assert s["final_points"] >= 2 * s["start_points"], s                # the model doubled ...
+    assert created >= 8, created                                       # ... and the workspace re-grew (5 kinds at first use)
+    before, after = s["psnr_train_before_after_db"]
+    assert after > before + 5.0, s
+    assert s["row_scans_carried"] > 0
+    # the repeat: same views, same densification decisions, same bits
+    s2, params2, _ = runs[1]
+    assert s2["final_points"] == s["final_points"] and [t[1] for t in s2["trace"]] == [t[1] for t in s["trace"]]
+    for a, b in zip(params, params2):
+        assert torch.equal(a, b)

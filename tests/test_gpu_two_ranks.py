@@ -14,6 +14,14 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _oracle_workers_off_the_card():
+    """The GPU boxes admit six processes on the card at once; the oracle farm's workers (tests/oracle_farm.py) count --
+    torch opens the device files at a process's first backward() -- so they finish and exit before ranks are started."""
+    from oracle_farm import FARM
+    FARM.drain()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -54,7 +62,10 @@ def _worker(rank, world, port, out_dir, factored, n=20000, w=320, h=200):
     broken = not vp.replicas_identical()
     vp.resync_from_rank0(m.optimizer)
     repaired = vp.replicas_identical()
-    torch.save({"params": [p.detach().cpu() for p in m.parameters()], "losses": losses, "same": same, "broken": broken,
+    # (at the 1 M-Gaussian preset the replicas are compared through their 64-bit fingerprints and every 64th row)
+    keep = [p.detach().cpu() for p in m.parameters()] if n <= 300_000 else \
+        [vp.replica_checksum().cpu()] + [p.detach()[::64].cpu() for p in m.parameters()]
+    torch.save({"params": keep, "losses": losses, "same": same, "broken": broken,
                 "repaired": repaired, "used_gather": vp._gathered is not None}, os.path.join(out_dir, f"r{rank}_{int(factored)}.pt"))
     dist.destroy_process_group()
 
@@ -82,14 +93,16 @@ def test_two_ranks_one_gpu_factored_and_explicit(gpu_device, tmp_path):
         assert abs(la - lb) <= 1e-5 * abs(lb)
 
 
-def test_four_ranks_truck_shape(gpu_device, tmp_path):
+@pytest.mark.parametrize("n", [200_000, 1_000_000], ids=["200k", "truck-preset-1M"])
+def test_four_ranks_truck_shape(gpu_device, tmp_path, n):
     """BASELINE config 4 (Tanks&Temples truck, view-parallel): the view-parallel step at the truck frame size, 979x543
     (identification/camera_loader.py:125), with FOUR ranks on one MI355X -- the box admits at most six processes on the
     card, this test process included, so the 8-rank run itself belongs to the driver's 8-GPU node; the 8-view form of
     gsr_adam_sh_factored is covered in test_gpu_factored_sh.py.  Every rank renders its own view; geometry gradients are
-    all-reduced, the four colour-gradient records all-gathered; replicas must stay bit-identical."""
+    all-reduced, the four colour-gradient records all-gathered; replicas must stay bit-identical.  Second case (round 4):
+    the truck PRESET itself, 1 M Gaussians at 979x543 (bench.py --preset truck), four replicas of it on the one card."""
     world = 4
-    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), True, 200_000, 979, 543), nprocs=world, join=True,
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), True, n, 979, 543), nprocs=world, join=True,
                        start_method="spawn")
     r = [torch.load(os.path.join(tmp_path, f"r{k}_1.pt")) for k in range(world)]
     assert all(x["used_gather"] and x["same"] and x["broken"] and x["repaired"] for x in r)

@@ -6,6 +6,7 @@ import torch
 
 from conftest import facing_scene, hip_settings
 from gaussmart_amd.synthetic import activate
+from oracle_farm import FARM, spec, check_gradient_bars
 from test_gpu_rasterizer import _grad_compare
 
 pytestmark = pytest.mark.gpu
@@ -21,16 +22,23 @@ def _wide_inputs(n, w, h, C, seed):
     return b, cam, bg
 
 
-@pytest.mark.parametrize("C,n,w,h", [(4, 1500, 200, 120), (16, 2000, 256, 256), (24, 800, 130, 70), (64, 1200, 192, 160)])
-def test_wide_payload_forward_backward_parity(gpu_device, C, n, w, h):
-    b, cam, bg = _wide_inputs(n, w, h, C, seed=C)
-    stats, (c_h, c_o) = _grad_compare(b, cam, gpu_device, 3, bg=bg)
-    assert c_h.shape == (C, h, w)
-    scale = float(c_o.detach().abs().max())
-    assert float((c_h.double() - c_o.detach()).abs().max()) < 5e-3 * max(1.0, scale)
-    assert float((c_h.double() - c_o.detach()).abs().median()) < 1e-5
-    for k, s in stats.items():
-        assert s["normwise"] < 1e-3 and s["median"] < 1e-4 and s["p99"] < 2e-3, (k, s)
+# (the oracle side of every case runs in a worker process from the start of the session: tests/oracle_farm.py)
+WIDE = {C: FARM.register(f"wide-C{C}-{n}@{w}x{h}", spec("facing", n, w, h, C, wide=(C, 100 + C), sens_tols=(1e-3,)))
+        for C, n, w, h in ((4, 1500, 200, 120), (16, 2000, 256, 256), (24, 800, 130, 70), (64, 1200, 192, 160))}
+WIDE_BIG = {C: FARM.register(f"wide-screen-filling-C{C}", spec("facing", 300, 160, 128, 12, radius_px=45.0, opa_const=0.05, wide=(C, C), sens_tols=(1e-3,)))
+            for C in (8, 24)}
+
+
+@pytest.mark.oracle_cases(*WIDE.values())
+@pytest.mark.parametrize("C", sorted(WIDE))
+def test_wide_payload_forward_backward_parity(gpu_device, C):
+    sp = FARM.specs[WIDE[C]]
+    stats, stats32, c_h, c_o, res = _grad_compare(WIDE[C], gpu_device)
+    assert c_h.shape == (C, sp["h"], sp["w"])
+    scale = float(c_o.abs().max())
+    assert float((c_h - c_o).abs().max()) < 5e-3 * max(1.0, scale)
+    assert float((c_h - c_o).abs().median()) < 1e-5
+    check_gradient_bars(WIDE[C], stats, stats32, flips=res["flips"])
 
 
 def test_wide_payload_first_three_channels_equal_rgb_path(gpu_device):
@@ -112,19 +120,13 @@ def test_wide_payload_nothing_visible(gpu_device):
     assert float(col.grad.abs().max()) == 0.0 and float(am.detach().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("C", [8, 24])
+@pytest.mark.oracle_cases(*WIDE_BIG.values())
+@pytest.mark.parametrize("C", sorted(WIDE_BIG))
 def test_wide_payload_screen_filling_splats(gpu_device, C):
     """Splats with thousands of gradient rows each: the feature-row reduction hands them to the whole workgroup
     (reduce_feat_rows_kernel, like reduce_rows); checked against the oracle with faint splats, so every one of them is
     blended far down the lists.  C = 24: 6 pieces per Gaussian, which does not divide the 256-thread workgroup."""
-    from test_gpu_deep_lists import _deep_scene
-    n, w, h = 300, 160, 128
-    a, cam = _deep_scene(n, w, h, 45.0, 12, 0.0, 0.05)
-    g = torch.Generator().manual_seed(C)
-    b = dict(means3D=a["means3D"], opacities=a["opacities"], scales=a["scales"], rotations=a["rotations"],
-             colors_precomp=torch.randn(n, C, generator=g))
-    bg = tuple(float(x) for x in torch.rand(C, generator=g))
-    stats, (c_h, c_o) = _grad_compare(b, cam, gpu_device, 3, bg=bg)
-    assert float((c_h.double() - c_o.detach()).abs().max()) < 5e-3 * max(1.0, float(c_o.detach().abs().max()))
+    stats, stats32, c_h, c_o, _ = _grad_compare(WIDE_BIG[C], gpu_device)
+    assert float((c_h - c_o).abs().max()) < 5e-3 * max(1.0, float(c_o.abs().max()))
     for k, s in stats.items():
         assert s["median"] < 1e-4 and s["p99"] < 2e-3, (k, s)
