@@ -124,12 +124,24 @@ def pmc_traffic(kernel):
     return int(FETCH_FACTOR[cls] * k["fetch_kb"] * 1024 + k["write_kb"] * 1024), raw
 
 
-# measured (round 3): scripts/microbench/valu_rate.hip, independent wave64 v_fma_f32 as inline assembly, 8 waves per SIMD,
-# whole chip: 764 G wave-instructions/s (3.2 cycles per instruction and SIMD at 2.4 GHz); compare + select and DPP adds
-# 536 G/s, v_rcp_f32 273 G/s.  SQ_INSTS_VALU reads 1.001x the known instruction count of those loops
-# (profiles/r03_valu_calib.json; scripts/valu_calib.sh).  Round 2 quoted 922: its loop had been SLP-packed into
-# v_pk_fma_f32 and the packed rate was counted twice.
-VALU_CEILING_GINST_S = 764.0
+# Vector-issue accounting of the dominant kernel (round 4).  The bound is MI355X_MICROARCH.md's: a SIMD issues one wave64
+# vector instruction per 2 cycles (1,024 SIMDs), at the clock the chip HOLDS while the kernel runs -- measured inside the
+# kernels with s_memtime / s_memrealtime (make PROBES=1, scripts/dev_clock_probe.py, profiles/r04_notes/clock_probe_k6_k7.json:
+# 2.37 GHz under render_fwd / render_bwd; only an all-FMA loop is power-limited, to 1.86-1.89 GHz, which is what round 3's
+# "764 G wave-instructions/s at 2.4 GHz" really was).  Priced kind by kind on this chip (scripts/microbench/valu_rate.hip,
+# profiles/r04_notes/valu_rate_kinds.txt: plain 2.4 cycles, DPP 4.3-5.5, SGPR-writing compares 4.4, transcendentals 8.3) the
+# instruction mix of render_bwd's loop costs 2.9-3.1 cycles per instruction, i.e. it could reach ~0.68 of the 2-cycle bound.
+N_SIMD = 1024
+VALU_BOUND_CYCLES = 2.0
+VALU_MIX_CYCLES = {"render_bwd": 3.0, "render_fwd": 3.0}     # per instruction, from the per-kind rates x the loop's mix
+
+
+def measured_clock_mhz(kernel):
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_notes", "clock_probe_k6_k7.json")) as f:
+            return float(json.load(f)[kernel]["clock_mhz"])
+    except (OSError, KeyError, TypeError, ValueError):
+        return None
 
 
 def pmc_valu_insts(kernel):
@@ -522,6 +534,24 @@ def main():
     step_ms_chrono = list(step_ms)
     step_ms.sort()
     median_ms = 0.5 * (step_ms[4] + step_ms[5])
+    # (a') the same step with the forward building ALL seven allmap channels.  By default the fused trainer does not accumulate
+    # the channels its objective cannot read in this configuration -- distortion and median depth at lambda_dist = 0 and
+    # depth_ratio = 0, the reference's defaults -- which changes no loss value, gradient or parameter by a single bit
+    # (tests/test_gpu_rasterizer.py::test_forward_without_distortion_and_median_equals_the_general_one_elsewhere); the line
+    # carries both rates so that nobody has to take that on trust.
+    full_maps = None
+    if not dropin and getattr(pipe, "color_only_when_unregularized", False):
+        pipe.color_only_when_unregularized = False
+        for i in range(5):
+            step(args.warmup + args.steps + n_post + i)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for i in range(n_post):
+            step(args.warmup + args.steps + n_post + 5 + i)
+        torch.cuda.synchronize()
+        full_maps = {"ms_per_step": (time.perf_counter() - tf0) / n_post * 1e3, "steps": n_post}
+        full_maps["value"] = world * 1e3 / full_maps["ms_per_step"]
+        pipe.color_only_when_unregularized = True
     comm_exposed_ms = comm_waits = None
     if vp is not None:
         exp_ms, n_waits = vp.exposed_ms()
@@ -603,10 +633,14 @@ def main():
                                if args.eval_flags else "L1 + SSIM + normal consistency (lambda_normal 0.05, lambda_dist 0)",
                        "step_pipeline": ("SH Adam update + next colour pass on a side stream beside the next forward's binning; "
                                          "every step renders the SAME view, so the optimiser step always leaves the next "
-                                         "forward's SH colours (colour cache hit on every step)" if next_cam is not None else
+                                         "forward's SH colours (colour cache hit on every step); the forward accumulates only the "
+                                         "allmap channels this objective reads (no distortion / median depth at lambda_dist = 0, "
+                                         "depth_ratio = 0; none at all with --eval-flags)" if next_cam is not None else
                                          "SH Adam update on a side stream beside the next forward's binning")
                                         if (vp is not None and (vp.overlap_local or world > 1 or force_dp)) else "serial"},
             "ms_per_step_median": median_ms,
+            # the step with every allmap channel accumulated in the forward (see (a') above); `value` is the default step
+            "with_all_seven_allmap_channels": full_maps,
             "ms_per_step_chunks": [round(x, 4) for x in step_ms_chrono],      # 10 chunks of consecutive steps, in order
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw,
@@ -620,13 +654,20 @@ def main():
                                     "achieved": achieved_walked, "frac": achieved_walked / HBM_PEAK_GBS}},
             # the dominant kernels are VALU-bound: the same launch priced against the MEASURED
             # vector-issue ceiling of the chip instead of the HBM roofline (informational, not the contract's roofline)
-            "valu_issue": (lambda n: None if not n or per_kernel[dom] <= 0 else {
+            "valu_issue": (lambda n, clk: None if not n or not clk or per_kernel[dom] <= 0 else {
                 "kernel": dom, "valu_wave_insts_per_launch": n, "achieved_ginst_s": n / (per_kernel[dom] * 1e-3) / 1e9,
-                "ceiling_ginst_s": VALU_CEILING_GINST_S, "frac": n / (per_kernel[dom] * 1e-3) / 1e9 / VALU_CEILING_GINST_S,
-                "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU, calibrated 1.001x on known counts); ceiling: independent "
-                          "v_fma_f32, scripts/microbench/valu_rate.hip + profiles/r03_valu_calib.json -- a kernel's mix also "
-                          "holds 4.6-cycle (compare, select, DPP) and 9-cycle (rcp, exp) instructions"})(
-                    pmc_valu_insts(dom) if headline else None),
+                "clock_mhz": clk,
+                "cycles_per_instr_per_simd": N_SIMD * clk * 1e6 * per_kernel[dom] * 1e-3 / n,
+                "bound_cycles_per_instr": VALU_BOUND_CYCLES,
+                "frac": VALU_BOUND_CYCLES / (N_SIMD * clk * 1e6 * per_kernel[dom] * 1e-3 / n),
+                "mix_cycles_per_instr": VALU_MIX_CYCLES.get(dom),
+                "frac_of_what_the_mix_allows": (VALU_MIX_CYCLES[dom] / (N_SIMD * clk * 1e6 * per_kernel[dom] * 1e-3 / n))
+                if dom in VALU_MIX_CYCLES else None,
+                "source": "instructions: profiles/pmc_traffic.json (SQ_INSTS_VALU, calibrated 1.0001x on known counts); clock: "
+                          "in-kernel s_memtime / s_memrealtime (profiles/r04_notes/clock_probe_k6_k7.json); bound: 2 cycles per "
+                          "wave64 instruction per SIMD (MI355X_MICROARCH.md); mix: per-kind rates of "
+                          "scripts/microbench/valu_rate.hip x the loop's instruction mix (DESIGN.md section 5)"})(
+                    pmc_valu_insts(dom) if headline else None, measured_clock_mhz(dom)),
             "hbm_peak_gb": {"allocated": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
                             "reserved": round(torch.cuda.max_memory_reserved(dev) / 2**30, 2)},
             "reference_iter_time_ms": ref_iter_ms,    # median of the reference's fwd+loss+bwd bracket (no Adam)

@@ -31,6 +31,7 @@ GSR_FLAG_DEBUG_RECT_CULL_ONLY = 64
 GSR_FLAG_COLOR_CACHED = 256      # shs + colour cache of this view (gsr_adam_sh_factored_next): no SH colour pass
 GSR_FLAG_FORWARD_ONLY = 128      # inference: keep nothing for a backward (no touch words, no per-pixel state)
 GSR_FLAG_AABB_GRAD_CUTOFF1 = 512  # recalled quirk 3: centre gradient chained with weights (1, 1, -1) (include/gsr.h)
+GSR_FLAG_NO_DIST_MEDIAN = 4096   # forward + backward: distortion and median depth are not consumed (lambda_dist = 0, depth_ratio = 0)
 GSR_FLAG_COLOR_ONLY = 2048       # forward: allmap is not consumed (no regularizer active): not accumulated, not written
 GSR_FLAG_NO_SURFACE_GRAD = 1024  # backward: dL/dallmap is identically zero (no regularizer active): 4-part-record kernel
 GSR_FLAG_FACTORED_SH_GRAD = 32   # backward writes the masked colour gradient [N,3] instead of the SH gradient arrays

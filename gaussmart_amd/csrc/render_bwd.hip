@@ -129,7 +129,9 @@ __global__ void __launch_bounds__(RB_BLOCK, NOSURF ? 8 : RB_MIN_WAVES) render_bw
     }
     const float bg_dot_dpixel = p.bg[0] * dL_dpix0 + p.bg[1] * dL_dpix1 + p.bg[2] * dL_dpix2;
 
-    const bool quad_has_dist = !NOSURF && __any(dL_dreg != 0.f), quad_has_median = !NOSURF && __any(dL_dmedian != 0.f);   // wave-uniform
+    // (GSR_FLAG_NO_DIST_MEDIAN: the forward returned channels 5 and 6 as constants -- gradients sent to them are ignored)
+    const bool dm_live = !NOSURF && (p.flags & (uint32_t)GSR_FLAG_NO_DIST_MEDIAN) == 0;
+    const bool quad_has_dist = dm_live && __any(dL_dreg != 0.f), quad_has_median = dm_live && __any(dL_dmedian != 0.f);   // wave-uniform
     const bool quad_has_surf = !NOSURF && __any(dL_ddepth != 0.f || dL_daccum != 0.f || dL_dn0 != 0.f || dL_dn1 != 0.f || dL_dn2 != 0.f);
 
     // running state of the back-to-front recursion

@@ -95,13 +95,18 @@ __device__ __forceinline__ uint32_t row_or_step(uint32_t v) {
 // leaving a pair early: the RGB kernel goes straight to the next entry; the wide kernel still owes the entry its MFMA
 // (a plain block, NOT do { } while (0): `continue` must reach the loop over the surviving entries)
 #define RF_NEXT_PAIR { if (FEAT16 > 0) goto pair_done; else continue; }
-// MAPS = false (round 4; GSR_FLAG_COLOR_ONLY): the caller does not consume allmap -- the fused trainer while no regularizer
-// is active (the first 7,000 iterations of every run, train.py:132-133, and the reference's evaluation flags,
-// scripts/dtu_eval.py:45) -- so depth, normal, median depth and distortion are not accumulated (the distortion arithmetic
-// alone, one reciprocal included, was 10 % of the kernel: DESIGN_history.md, probe 2), allmap is not written and the image
-// state keeps only T and the last contributor.  Colour, T, radii, touch words and row counts are those of the general kernel
-// bit for bit; the backward of such a forward runs without the surface terms (GSR_FLAG_NO_SURFACE_GRAD).
-template <int FEAT16, bool SAVE, int PROBE = 0, bool MAPS = true>
+// MAPS (round 4): which allmap channels the caller consumes.
+//   2  all seven (the reference operator).
+//   1  GSR_FLAG_NO_DIST_MEDIAN: not the distortion and the median depth -- the reference's DEFAULT training configuration
+//      (lambda_dist = 0, arguments/__init__.py:87; depth_ratio = 0, :72: surf_depth is the expected depth alone,
+//      gaussian_renderer/__init__.py:141).  The distortion arithmetic (one reciprocal included) is 10 % of the kernel
+//      (DESIGN_history.md, probe 2); channels 5 and 6 and the M1 / M2 / median-contributor state come back as zeros / -1, and
+//      the backward ignores gradients sent to those two channels (they are constants).
+//   0  GSR_FLAG_COLOR_ONLY: none -- the fused trainer while no regularizer is active (the first 7,000 iterations of every
+//      run, train.py:132-133, and the reference's evaluation flags, scripts/dtu_eval.py:45): allmap is not written, the
+//      image state keeps only T and the last contributor, the backward runs under GSR_FLAG_NO_SURFACE_GRAD.
+// Colour, T, the remaining channels, radii, touch words and row counts are those of the general kernel bit for bit.
+template <int FEAT16, bool SAVE, int PROBE = 0, int MAPS = 2>
 __global__ void __launch_bounds__(RF_BLOCK, FEAT16 == 0 ? RF_MIN_WAVES : (FEAT16 == 1 ? 5 : FEAT16 == 2 ? 4 : 3)) render_fwd_kernel(RenderFwdParams p) {
     __shared__ float4 s_rec_all[RF_WAVES][64 * 5];
     const int tid = threadIdx.x;
@@ -242,7 +247,7 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
             if (test_T < GSR_T_EPS) { done = true; RF_NEXT_PAIR; }
             const float4 a4 = PROBE == 3 ? a3 : s_rec[j * 5 + 4];
             const float w = alpha * T;
-            if (MAPS) {
+            if (MAPS == 2) {
                 const float A = 1.0f - T;
                 float dm_dz_unused;
                 const float m_d = PROBE == 5 ? depth : gsr_depth_map(depth, dm_dz_unused);
@@ -251,8 +256,10 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
                     M1 += m_d * w;
                     M2 += m_d * m_d * w;
                 }
-                Dacc += depth * w;
                 if (T > 0.5f) { med_depth = depth; med_contrib = contributor; }
+            }
+            if (MAPS >= 1) {
+                Dacc += depth * w;
                 N0 += a2.w * w; N1 += a3.x * w; N2 += a3.y * w;
             }
             if (FEAT16 == 0) { C0 += a3.w * w; C1 += a4.x * w; C2 += a4.y * w; }
@@ -305,7 +312,7 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
         if (SAVE) {
             p.final_T[pix_id] = T;
             p.n_contrib[pix_id] = last_contributor;
-            if (MAPS) {
+            if (MAPS >= 1) {      // (MAPS == 1: zeros and "no median contributor" -- the accumulators were never touched)
                 p.final_T[pix_id + HW] = M1;
                 p.final_T[pix_id + 2 * HW] = M2;
                 p.n_contrib[pix_id + HW] = med_contrib;
@@ -316,7 +323,7 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
             p.out_color[pix_id + HW] = C1 + T * p.bg[1];
             p.out_color[pix_id + 2 * HW] = C2 + T * p.bg[2];
         }
-        if (MAPS) {
+        if (MAPS >= 1) {
             p.out_allmap[pix_id + 0 * HW] = Dacc;
             p.out_allmap[pix_id + 1 * HW] = 1.0f - T;
             p.out_allmap[pix_id + 2 * HW] = N0;
@@ -419,7 +426,8 @@ int gsr_launch_render_fwd(const GsrView& v, const uint32_t* ranges, const float*
     const dim3 grid(8 * p.per_xcd), block(RF_BLOCK);
     if (feat == nullptr) {
         if (v.flags & (uint32_t)GSR_FLAG_FORWARD_ONLY) hipLaunchKernelGGL((render_fwd_kernel<0, false>), grid, block, 0, s, p);
-        else if (v.flags & (uint32_t)GSR_FLAG_COLOR_ONLY) hipLaunchKernelGGL((render_fwd_kernel<0, true, 0, false>), grid, block, 0, s, p);
+        else if (v.flags & (uint32_t)GSR_FLAG_COLOR_ONLY) hipLaunchKernelGGL((render_fwd_kernel<0, true, 0, 0>), grid, block, 0, s, p);
+        else if (v.flags & (uint32_t)GSR_FLAG_NO_DIST_MEDIAN) hipLaunchKernelGGL((render_fwd_kernel<0, true, 0, 1>), grid, block, 0, s, p);
         else {
 #ifdef GSR_DEV_PROBES
             const char* e = getenv("GSR_K6_PROBE");   // re-read per launch

@@ -11,6 +11,8 @@ The extra keyword `surface_maps=False` skips the five derived maps: the trainer'
 optimiser step) makes the backward leave the colour gradient [N,3] instead of the two SH gradient tensors.
 `color_only=True` (raw-parameter path with `surface_maps=False`; set by trainer.training_step while no regularizer is
 active, i.e. before iteration 7,000 or with lambda_normal = lambda_dist = 0): "allmap" comes back as None.
+`no_dist_median=True` (same path; set while lambda_dist = 0 and depth_ratio = 0, the reference's defaults): channels 5
+(median depth) and 6 (distortion) of "allmap" come back as zeros -- nobody reads them in that configuration.
 
 Device follows the model's tensors (the reference hard-codes "cuda").
 """
@@ -110,7 +112,7 @@ def _use_raw_path(pc, pipe, override_color, xyz):
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, *,
-           surface_maps=True, factored_sh_grad=False, color_only=False):
+           surface_maps=True, factored_sh_grad=False, color_only=False, no_dist_median=False):
     xyz = pc.get_xyz
     device = xyz.device
     # the reference adds 0 and calls retain_grad() (gaussian_renderer/__init__.py:27-31); a leaf that requires
@@ -174,7 +176,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         rendered_image, radii, allmap = rasterize_gaussians_raw(
             xyz, means2D, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation, raster_settings,
             factored_sh_grad=factored and state is not None, color_cache=cache if state is not None else None, state=state,
-            color_only=bool(color_only) and not surface_maps and torch.is_grad_enabled())
+            color_only=bool(color_only) and not surface_maps and torch.is_grad_enabled(),
+            no_dist_median=bool(no_dist_median) and not surface_maps and torch.is_grad_enabled())
     else:
         rendered_image, radii, allmap = rasterizer(
             means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,

@@ -438,7 +438,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings, flags,
-                color_cache=None, state=None, color_only=False):
+                color_cache=None, state=None, color_only=False, no_dist_median=False):
         L = _lib.lib()
         device = xyz.device
         if device.type != "cuda":
@@ -455,6 +455,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         flags = int(flags) | _lib.GSR_FLAG_RAW_PARAMS
         if color_only:                    # the caller does not consume allmap (no regularizer active): not accumulated, not written
             flags |= _lib.GSR_FLAG_COLOR_ONLY
+        elif no_dist_median:              # ... or not its distortion / median-depth channels (lambda_dist = 0, depth_ratio = 0)
+            flags |= _lib.GSR_FLAG_NO_DIST_MEDIAN
         if color_cache is not None:       # the SH colour of this view was left by the optimiser step (FusedAdam.color_cache)
             if color_cache.numel() != 13 * N or color_cache.dtype != torch.float32 or color_cache.device != device:
                 raise ValueError("color_cache must be float32 [13 N] on the parameters' device")
@@ -583,7 +585,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         _finish_lease(ctx)
         if factored:
             ctx.state.color_grad = ColorGradRecord(flat, flat[:n_head], record, N, ctx.M, rs.sh_degree, xyz)
-        return d_xyz, d_2d, d_dc, d_rest, d_op, d_sc, d_rot, None, None, None, None, None
+        return d_xyz, d_2d, d_dc, d_rest, d_op, d_sc, d_rot, None, None, None, None, None, None
 
 
 def _wants_grad(*tensors):
@@ -618,7 +620,8 @@ def _forward_only(device, rs, flags, sh_coeffs, gaussians_args, N):
 
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
-                            raster_settings, flags=None, factored_sh_grad=False, color_cache=None, state=None, color_only=False):
+                            raster_settings, flags=None, factored_sh_grad=False, color_cache=None, state=None, color_only=False,
+                            no_dist_median=False):
     """(color, radii, allmap) from the model's raw parameter tensors; activations fused in-kernel.
     `state`: the model's RasterState (hand-over slots with the optimiser step); None for a caller that has neither a
     pipelined update in flight nor a factored gradient to receive.
@@ -626,7 +629,9 @@ def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_ra
     `state.color_grad` (RasterState.take_color_grad) for FusedAdam.step_sh_factored instead -- only for callers that own
     the optimiser step, and only with a `state` to leave it in.
     `color_only`: the caller consumes the colour image alone (a training step with no regularizer active): allmap comes back
-    as None -- the forward neither accumulates nor writes it (GSR_FLAG_COLOR_ONLY), the backward runs without its terms."""
+    as None -- the forward neither accumulates nor writes it (GSR_FLAG_COLOR_ONLY), the backward runs without its terms.
+    `no_dist_median`: the caller consumes neither the distortion nor the median-depth channel of allmap (lambda_dist = 0 and
+    depth_ratio = 0, the reference's defaults): both come back as zeros (GSR_FLAG_NO_DIST_MEDIAN)."""
     flags = DEFAULT_FLAGS if flags is None else flags
     if factored_sh_grad and state is None:
         raise ValueError("factored_sh_grad needs state=RasterState(): the backward leaves its colour-gradient record there")
@@ -646,7 +651,8 @@ def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_ra
         flags |= _lib.GSR_FLAG_FACTORED_SH_GRAD
     color, radii, allmap = _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
                                                         rotation_raw, raster_settings, flags,
-                                                        color_cache if factored_sh_grad else None, state, bool(color_only))
+                                                        color_cache if factored_sh_grad else None, state, bool(color_only),
+                                                        bool(no_dist_median))
     return color, radii, (None if color_only else allmap)
 
 

@@ -100,9 +100,12 @@ def training_step(gaussians, viewpoint_cam, gt_image, opt, pipe, background, ite
         # while no regularizer is active (train.py:132-133: lambda_normal from iteration 7,000, lambda_dist from 3,000 and 0 by
         # default; scripts/dtu_eval.py:45 trains with both at 0) nobody reads allmap: the forward does not build it
         no_reg = not ((opt.lambda_normal > 0.0 and iteration > 7000) or (opt.lambda_dist > 0.0 and iteration > 3000))
+        lean = getattr(pipe, "color_only_when_unregularized", True) and _rasterizer._NO_SURFACE_FAST_PATH   # (=0: A/B aid)
+        # ... and with the reference's defaults (lambda_dist = 0, depth_ratio = 0: arguments/__init__.py:72,87) nobody ever reads
+        # the distortion and median-depth channels: the forward does not accumulate them
+        no_dm = not (opt.lambda_dist > 0.0 and iteration > 3000) and float(getattr(pipe, "depth_ratio", 0.0)) == 0.0
         render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=False, factored_sh_grad=True,
-                               color_only=no_reg and getattr(pipe, "color_only_when_unregularized", True)
-                               and _rasterizer._NO_SURFACE_FAST_PATH)      # (GSR_NO_SURFACE_FAST_PATH=0: A/B aid)
+                               color_only=no_reg and lean, no_dist_median=no_dm and lean)
     else:
         render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=not on_device)
     # (the backward follows at once: the loss scalars are written by a workgroup of its first kernel, not by a launch of

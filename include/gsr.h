@@ -81,6 +81,12 @@ enum {
                                        pass would run (same position in the stream, same GSR_FLAG_DEFER_COLOR handling) and
                                        never reads the coefficients; gsr_backward (pass the same pointer and flag) takes
                                        d(rgb)/d(dir) from the cache.  The caller guarantees that the cache matches */
+    GSR_FLAG_NO_DIST_MEDIAN = 4096, /* gsr_forward + gsr_backward (RGB payload): the caller consumes neither the distortion (allmap
+                                       channel 6) nor the median depth (channel 5) -- the reference's default training configuration,
+                                       lambda_dist = 0 and depth_ratio = 0 (arguments/__init__.py:72,87).  Both channels come back
+                                       as zeros (not accumulated: the distortion arithmetic is 10 % of the forward), the other five
+                                       and the colour are those of the general forward bit for bit; the backward treats the two
+                                       channels as constants */
     GSR_FLAG_COLOR_ONLY = 2048,     /* gsr_forward (RGB payload, not with GSR_FLAG_FORWARD_ONLY): the caller does not consume allmap -- a
                                        trainer while no regularizer is active.  out->allmap is NOT written, the kept image state
                                        holds T and the last contributor only; colour, radii and everything the backward walks are

@@ -381,6 +381,31 @@ def test_no_surface_gradient_kernel_is_bit_identical(gpu_device, monkeypatch, n,
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("n,w,h,seed,radius", [(20000, 320, 240, 5, 6.0), (8000, 64, 64, 0, 14.0)])
+def test_forward_without_distortion_and_median_equals_the_general_one_elsewhere(gpu_device, n, w, h, seed, radius):
+    """GSR_FLAG_NO_DIST_MEDIAN (the reference's default configuration: lambda_dist = 0, depth_ratio = 0): channels 5 and 6 of
+    allmap come back as zeros, everything else -- colour, the other five channels, radii, and every gradient of a loss that
+    reads them -- equals the general forward / backward bit for bit; gradients sent to the two constant channels are ignored."""
+    from gaussmart_amd import rasterizer as R
+    p, cam = make_scene(n, w, h, seed=seed, radius_px=radius)
+    g = torch.Generator().manual_seed(seed + 3)
+    wc, wa = torch.randn(3, h, w, generator=g).to(gpu_device), torch.randn(7, h, w, generator=g).to(gpu_device)
+    outs = []
+    for lean in (False, True):
+        pr = {k: v.clone().to(gpu_device).requires_grad_(True) for k, v in p.items()}
+        m2 = torch.zeros(n, 3, device=gpu_device, requires_grad=True)
+        c, r, am = R.rasterize_gaussians_raw(pr["xyz"], m2, pr["features_dc"], pr["features_rest"], pr["opacity"], pr["scaling"],
+                                             pr["rotation"], hip_settings(cam, 3, (0.1, 0.2, 0.3), gpu_device), no_dist_median=lean)
+        # the general run differentiates the first five channels only; the lean run ALSO sends gradient to channels 5, 6
+        ((c * wc).sum() + (am[:5] * wa[:5]).sum() + ((am[5:] * wa[5:]).sum() if lean else 0.0)).backward()
+        outs.append([c.detach(), am.detach(), r] + [pr[k].grad for k in pr] + [m2.grad])
+    gen, lean = outs
+    assert torch.equal(gen[0], lean[0]) and torch.equal(gen[2], lean[2])
+    assert torch.equal(gen[1][:5], lean[1][:5]) and float(lean[1][5:].abs().max()) == 0.0 and float(gen[1][6].abs().max()) > 0.0
+    for x, y in zip(gen[3:], lean[3:]):
+        assert torch.equal(x, y)
+
+
 def test_bitwise_deterministic(gpu_device):
     from gaussmart_amd.rasterizer import GaussianRasterizer
     p, cam = make_scene(20000, 320, 240, seed=5)
