@@ -149,7 +149,7 @@ def lib():
         L.gsr_backward_with_job.argtypes = L.gsr_backward.argtypes[:10] + [C.POINTER(GsrRowScanJob)] + \
             L.gsr_backward.argtypes[10:]
         L.gsr_loss_forward_job.restype = C.c_int32
-        L.gsr_loss_forward_job.argtypes = L.gsr_loss_forward.argtypes[:-1] + [C.POINTER(GsrRowScanJob), C.c_void_p]
+        L.gsr_loss_forward_job.argtypes = L.gsr_loss_forward.argtypes[:-1] + [C.POINTER(GsrRowScanJob), C.c_void_p, C.c_void_p]
         L.gsr_loss_backward_finish.restype = C.c_int32
         L.gsr_loss_backward_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,

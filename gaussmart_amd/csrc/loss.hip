@@ -74,12 +74,15 @@ __device__ __forceinline__ void loss_hpass_row4(const float* __restrict__ row, c
 __global__ void __launch_bounds__(256, 3) loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
                                                        int C, int H, int W, float* __restrict__ maps,
                                                        float* __restrict__ partials, LossWindow win, int tile_wgs,
-                                                       RowScanArgs scan) {
+                                                       RowScanArgs scan, float* __restrict__ invalidate5) {
     __shared__ __attribute__((aligned(16))) float sx[LR][LSTR];
     __shared__ __attribute__((aligned(16))) float sy[LR][LSTR];
     __shared__ __attribute__((aligned(16))) float sh[4][LR][LT];
     __shared__ float red[2][4];
     const int t = threadIdx.x;
+    // deferred objective value (gsr_loss_backward_finish writes the five scalars): until then they read NaN, so that a value
+    // taken before -- or without -- the backward is visibly invalid (a torch.full for this was a 6 us launch per step)
+    if (invalidate5 && blockIdx.x == 0 && t < 5) invalidate5[t] = __builtin_nanf("");
     if ((int)blockIdx.x >= tile_wgs) {          // side job: first half of the row scan, one scan tile per workgroup
         __shared__ uint32_t wt[SCAN_BLOCK / 64];
         const int sb = (int)blockIdx.x - tile_wgs;
@@ -375,18 +378,19 @@ extern "C" int32_t gsr_loss_num_partials(int32_t H, int32_t W) {
 
 extern "C" int32_t gsr_loss_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W,
                                     float* maps, float* partials, gsr_stream_t stream_) {
-    return gsr_loss_forward_job(img, gt, C, H, W, maps, partials, nullptr, stream_);
+    return gsr_loss_forward_job(img, gt, C, H, W, maps, partials, nullptr, nullptr, stream_);
 }
 
 extern "C" int32_t gsr_loss_forward_job(const float* img, const float* gt, int32_t C, int32_t H, int32_t W,
-                                        float* maps, float* partials, GsrRowScanJob* job, gsr_stream_t stream_) {
+                                        float* maps, float* partials, GsrRowScanJob* job, float* out5_invalidate,
+                                        gsr_stream_t stream_) {
     if (!img || !gt || !maps || !partials || C <= 0 || H <= 0 || W <= 0) { gsr_set_error("bad loss_forward arguments"); return GSR_E_INVALID; }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     GsrProfileScope prof(GSR_K_LOSS_FWD, s);
     const unsigned tile_wgs = gsr_xcd_tile_grid(((W + LT - 1) / LT) * ((H + LT - 1) / LT));
     const RowScanArgs scan = make_row_scan(job, 0);
     hipLaunchKernelGGL(loss_fwd_kernel, dim3(tile_wgs + (unsigned)scan.blocks), dim3(256), 0, s, img, gt, C, H, W, maps, partials,
-                       make_window(), (int)tile_wgs, scan);
+                       make_window(), (int)tile_wgs, scan, out5_invalidate);
     GSR_LAUNCH_CHECK();
     if (scan.blocks > 0) job->stage = 1;
     return GSR_OK;

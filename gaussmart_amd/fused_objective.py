@@ -34,20 +34,20 @@ class _Objective(torch.autograd.Function):
             n_part = L.gsr_loss_num_partials(H, W)
             maps = torch.empty((3, Cn, H, W), dtype=torch.float32, device=dev)
             partials = torch.empty((2, n_part), dtype=torch.float32, device=dev)
-            # (with defer_value the five scalars are only written during the backward: until then they read NaN, so a value
-            # taken without a backward -- or before it -- is visibly invalid instead of uninitialised memory)
-            out = torch.full((5,), float("nan"), dtype=torch.float32, device=dev) if defer_value else \
-                torch.empty(5, dtype=torch.float32, device=dev)
+            # (with defer_value the five scalars are only written during the backward: until then they read NaN -- the loss
+            # forward's launch fills them in -- so a value taken without a backward, or before it, is visibly invalid)
+            out = torch.empty(5, dtype=torch.float32, device=dev)
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             # the scan the rasterizer's backward starts with rides along with these launches, if the forward that produced
             # `image` offered it (training_objective took the job from image.grad_fn)
             if not ctx.needs_input_grad[0]:
                 job = None
             ctx.row_scan_job = job
-            if job is not None:
+            if job is not None or defer_value:
                 _lib.check(L.gsr_loss_forward_job(C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()), Cn, H, W,
                                                   C.c_void_p(maps.data_ptr()), C.c_void_p(partials[0].data_ptr()),
-                                                  C.byref(job), stream))
+                                                  C.byref(job) if job is not None else None,
+                                                  C.c_void_p(out.data_ptr()) if defer_value else None, stream))
             else:
                 _lib.check(L.gsr_loss_forward(C.c_void_p(img.data_ptr()), C.c_void_p(tgt.data_ptr()), Cn, H, W,
                                               C.c_void_p(maps.data_ptr()), C.c_void_p(partials[0].data_ptr()), stream))

@@ -299,9 +299,11 @@ int32_t gsr_loss_backward_finish(const float* img, const float* gt, const float*
                                  float lambda_dist, float* out5 /* NULL: no scalars */,
                                  GsrRowScanJob* job /* NULL, or a job at stage 1: its second half rides along */,
                                  gsr_stream_t stream);
-/* gsr_loss_forward with the first half of a row-scan job (stage 0 -> 1) in extra workgroups of its launch. */
+/* gsr_loss_forward with the first half of a row-scan job (NULL, or stage 0 -> 1) in extra workgroups of its launch.
+ * out5_invalidate (may be NULL): five floats the launch fills with NaN -- the objective's scalars of a caller that lets
+ * gsr_loss_backward_finish write them later, so that a value read before that is visibly invalid. */
 int32_t gsr_loss_forward_job(const float* img, const float* gt, int32_t C, int32_t H, int32_t W,
-                             float* maps, float* partials, GsrRowScanJob* job, gsr_stream_t stream);
+                             float* maps, float* partials, GsrRowScanJob* job, float* out5_invalidate, gsr_stream_t stream);
 
 /* Dense Adam step over up to 8 parameter tensors in one launch; the update of
  * torch.optim.Adam as the reference configures it (scene/gaussian_model.py:282-295).  All arrays
