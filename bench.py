@@ -534,6 +534,12 @@ def main():
     step_ms_chrono = list(step_ms)
     step_ms.sort()
     median_ms = 0.5 * (step_ms[4] + step_ms[5])
+    comm_exposed_ms = comm_waits = None
+    if vp is not None:
+        exp_ms, n_waits = vp.exposed_ms()
+        comm_exposed_ms, comm_waits = exp_ms / n_post, n_waits / n_post
+        vp.probe = False
+    replicas_ok = vp.replicas_identical() if (vp is not None and (world > 1 or force_dp)) else None
     # (a') the same step with the forward building ALL seven allmap channels.  By default the fused trainer does not accumulate
     # the channels its objective cannot read in this configuration -- distortion and median depth at lambda_dist = 0 and
     # depth_ratio = 0, the reference's defaults -- which changes no loss value, gradient or parameter by a single bit
@@ -552,12 +558,6 @@ def main():
         full_maps = {"ms_per_step": (time.perf_counter() - tf0) / n_post * 1e3, "steps": n_post}
         full_maps["value"] = world * 1e3 / full_maps["ms_per_step"]
         pipe.color_only_when_unregularized = True
-    comm_exposed_ms = comm_waits = None
-    if vp is not None:
-        exp_ms, n_waits = vp.exposed_ms()
-        comm_exposed_ms, comm_waits = exp_ms / n_post, n_waits / n_post
-        vp.probe = False
-    replicas_ok = vp.replicas_identical() if (vp is not None and (world > 1 or force_dp)) else None
 
     # (b) the reference's own `iter_time` bracket (train.py:91,145: forward + loss + backward, no optimiser step) and
     # (c) inference frames the way render.py / view.py produce them (render() under no_grad: forward-only kernels)
