@@ -334,27 +334,32 @@ s_rec[lane * 5] = pf0; s_rec[lane * 5 + 1] = pf1; s_rec[lane * 5 + 2] = pf2; s_r
         }
     }
     if (FEAT16 > 0) {   // the accumulator tiles hold (pixel of block b, channel) pairs of OTHER lanes' pixels: see `acc`
-        float bgv[NM][4];
+        // Round 4: the [C, H, W] image leaves through the wave's LDS slice (the list walk is over), 16 channels at a time, so
+        // that ONE store instruction writes ONE channel plane: 8 rows of 32 bytes of the quad, lane = pixel.  Straight from
+        // the accumulator layout an instruction wrote 4 channels x 4 rows x 16 bytes -- sixteen 16-byte pieces, each charged a
+        // whole 64-byte sector (0.3 ms of the 1.6 ms at C = 64).
+        float* tile = reinterpret_cast<float*>(s_rec);                 // 16 channels x 65 floats (padded: rows hit distinct banks)
+        const int rqx = lane & 7, rqy = lane >> 3;                     // my pixel when the tile is read back: row-major in the quad
+        const int src_lane = 16 * ((rqy >> 2) * 2 + (rqx >> 2)) + (rqy & 3) * 4 + (rqx & 3);      // ... and the lane that composited it
+        const float Tq = __shfl(T, src_lane, 64);
+        const int opx = qx0 + rqx, opy = qy0 + rqy;
+        const bool oin = opx < p.W && opy < p.H;
+        const size_t opid = (size_t)opy * p.W + opx;
 #pragma unroll
-        for (int k = 0; k < NM; ++k)
+        for (int k = 0; k < NM; ++k) {
+            __builtin_amdgcn_wave_barrier();                           // the previous tile has been read
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ch = NM * (4 * grp + r) + k;
-                bgv[k][r] = ch < p.C ? p.bg[ch] : 0.f;
+            for (int v = 0; v < 16; ++v) {
+                const int bq = v >> 2;
+                const int q = ((bq >> 1) * 4 + (l16 >> 2)) * 8 + (bq & 1) * 4 + (l16 & 3);
+                tile[(4 * grp + (v & 3)) * 65 + q] = acc[k][v];
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const float Tb = __shfl(T, 16 * b + l16, 64);
-            const int pxb = qx0 + (b & 1) * 4 + (l16 & 3), pyb = qy0 + (b >> 1) * 4 + (l16 >> 2);
-            if (pxb < p.W && pyb < p.H) {
-                const size_t pidb = (size_t)pyb * p.W + pxb;
-#pragma unroll
-                for (int k = 0; k < NM; ++k)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ch = NM * (4 * grp + r) + k;
-                        if (ch < p.C) p.out_color[pidb + (size_t)ch * HW] = acc[k][4 * b + r] + Tb * bgv[k][r];
-                    }
+            for (int c = 0; c < 16; ++c) {
+                const int ch = NM * c + k;                             // (wave-uniform)
+                if (ch < p.C && oin) p.out_color[opid + (size_t)ch * HW] = tile[c * 65 + lane] + Tq * p.bg[ch];
             }
         }
     }
