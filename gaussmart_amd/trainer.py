@@ -45,7 +45,9 @@ def _unit_gradient(t):
 def training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam=None, pipe=None, defer_value=False):
     """train.py:113-143.  On a HIP device the whole objective (L1 + SSIM + surface regularizers) is
     one fused autograd node (gaussmart_amd/fused_objective.py); on the host (CPU plumbing tests)
-    the stock torch formulation of the reference is used on the maps render() derived."""
+    the stock torch formulation of the reference is used on the maps render() derived.
+    (The diagnostics follow what the forward was asked to build: "dist_mean" reads 0 while lambda_dist = 0 -- the reference
+    logs lambda_dist * mean there, i.e. 0 as well -- and "normal_mean" reads 0 while no regularizer is active.)"""
     image = render_pkg["render"]
     lambda_normal = opt.lambda_normal if iteration > 7000 else 0.0
     lambda_dist = opt.lambda_dist if iteration > 3000 else 0.0
