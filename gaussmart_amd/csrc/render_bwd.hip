@@ -114,11 +114,16 @@ __global__ void __launch_bounds__(RB_BLOCK, NOSURF ? 8 : RB_MIN_WAVES) render_bw
     const float final_A = 1.0f - T_final;
     const int median_contributor = (!NOSURF && inside) ? (int)p.n_contrib[pix_id + HW] : 0;
 
+    // A pixel nothing was blended into takes no part in the reference's backward (its loop over contributors is empty), so
+    // whatever gradient arrives for it must not be read: the replay below is branch-free -- an idle lane contributes
+    // 0 * (its pixel's gradient) to the 16-lane sums -- and the reference's OWN objective sends NaN to exactly these pixels
+    // (gaussian_renderer/__init__.py:131-132: depth / alpha with alpha = 0, nan_to_num on the value only).
+    const bool lit = inside && last_contributor > 0;
     float dL_dpix0 = 0.f, dL_dpix1 = 0.f, dL_dpix2 = 0.f;
     float dL_ddepth = 0.f, dL_daccum = 0.f, dL_dreg = 0.f, dL_dmedian = 0.f;
     float dL_dn0 = 0.f, dL_dn1 = 0.f, dL_dn2 = 0.f;
-    if (inside) { dL_dpix0 = p.dL_dcolor[pix_id]; dL_dpix1 = p.dL_dcolor[pix_id + HW]; dL_dpix2 = p.dL_dcolor[pix_id + 2 * HW]; }
-    if (!NOSURF && inside) {
+    if (lit) { dL_dpix0 = p.dL_dcolor[pix_id]; dL_dpix1 = p.dL_dcolor[pix_id + HW]; dL_dpix2 = p.dL_dcolor[pix_id + 2 * HW]; }
+    if (!NOSURF && lit) {
         dL_ddepth = p.dL_dallmap[pix_id + 0 * HW];
         dL_daccum = p.dL_dallmap[pix_id + 1 * HW];
         dL_dn0 = p.dL_dallmap[pix_id + 2 * HW];
@@ -295,7 +300,8 @@ __global__ void __launch_bounds__(RB_BLOCK, NOSURF ? 8 : RB_MIN_WAVES) render_bw
                 if (pr.use3d) {
                     const float dL_dsx = NOSURF ? dL_dG * (-G * sx) : dL_dG * (-G * sx) + dL_dz * Twx;
                     const float dL_dsy = NOSURF ? dL_dG * (-G * sy) : dL_dG * (-G * sy) + dL_dz * Twy;
-                    const float dpx = dL_dsx * inv_pz, dpy = dL_dsy * inv_pz;
+                    float dpx = dL_dsx * inv_pz, dpy = dL_dsy * inv_pz;
+                    if (pr.tiny_any) { const float zs = pr.tiny ? GSR_TINY_PZ_SCALE : 1.f; dpx *= zs; dpy *= zs; }   // (pair_eval.h: a denormal p.z)
                     const float dpz = -(dpx * sx + dpy * sy);
                     // dL/dTu = -dL/dk = dL/dp x l ;  dL/dTv = -dL/dl = k x dL/dp
                     const float ux = dpy * pr.lz - dpz * pr.ly, uy = dpz * pr.lx - dpx * pr.lz, uz = dpx * pr.ly - dpy * pr.lx;

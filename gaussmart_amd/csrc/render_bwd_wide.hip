@@ -72,14 +72,16 @@ __device__ __forceinline__ void render_bwd_wide_tile(const RenderBwdParams& p) {
     const float final_A = 1.0f - T_final;
     const int median_contributor = inside ? (int)p.n_contrib[pix_id + HW] : 0;
 
+    // (a pixel nothing was blended into takes no part, whatever gradient arrives for it: render_bwd.hip)
+    const bool lit = inside && last_contributor > 0;
     // dL/dpixel of MY pixel, all channels (lane = pixel): the B operand of the Q products
     constexpr int NF = 16 * NM;
     float g[NF];
 #pragma unroll
-    for (int k = 0; k < NF; ++k) g[k] = (inside && k < p.C) ? p.dL_dcolor[pix_id + (size_t)k * HW] : 0.f;
+    for (int k = 0; k < NF; ++k) g[k] = (lit && k < p.C) ? p.dL_dcolor[pix_id + (size_t)k * HW] : 0.f;
     float dL_ddepth = 0.f, dL_daccum = 0.f, dL_dreg = 0.f, dL_dmedian = 0.f;
     float dL_dn0 = 0.f, dL_dn1 = 0.f, dL_dn2 = 0.f;
-    if (inside) {
+    if (lit) {
         dL_ddepth = p.dL_dallmap[pix_id + 0 * HW];
         dL_daccum = p.dL_dallmap[pix_id + 1 * HW];
         dL_dn0 = p.dL_dallmap[pix_id + 2 * HW];
@@ -265,7 +267,8 @@ __device__ __forceinline__ void render_bwd_wide_tile(const RenderBwdParams& p) {
                     if (pr.use3d) {
                         const float dL_dsx = dL_dG * (-G * sx) + dL_dz * Twx;
                         const float dL_dsy = dL_dG * (-G * sy) + dL_dz * Twy;
-                        const float dpx = dL_dsx * inv_pz, dpy = dL_dsy * inv_pz;
+                        float dpx = dL_dsx * inv_pz, dpy = dL_dsy * inv_pz;
+                        if (pr.tiny_any) { const float zs = pr.tiny ? GSR_TINY_PZ_SCALE : 1.f; dpx *= zs; dpy *= zs; }   // (pair_eval.h: a denormal p.z)
                         const float dpz = -(dpx * sx + dpy * sy);
                         const float ux = dpy * pr.lz - dpz * pr.ly, uy = dpz * pr.lx - dpx * pr.lz, uz = dpx * pr.ly - dpy * pr.lx;
                         const float vx = pr.ky * dpz - pr.kz * dpy, vy = pr.kz * dpx - pr.kx * dpz, vz = pr.kx * dpy - pr.ky * dpx;

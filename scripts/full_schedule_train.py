@@ -41,15 +41,25 @@ PRESETS = {   # name: (N, W, H, mean projected 3-sigma radius in px) -- bench.py
 }
 
 
-def all_finite(model):
-    ts = [p.detach() for p in model.parameters()]
-    for st in model.optimizer.state.values():
-        ts += [st[k] for k in ("exp_avg", "exp_avg_sq") if k in st]
-    return bool(torch.stack([torch.isfinite(t).all() for t in ts if t.numel()]).all().item())
+def all_finite(model, report=None):
+    names = ["xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation"]
+    ts = [(n, p.detach()) for n, p in zip(names, model.parameters())]
+    for n, p in zip(names, model.parameters()):
+        st = model.optimizer.state.get(p, {})
+        ts += [(f"{n}.{k}", st[k]) for k in ("exp_avg", "exp_avg_sq") if k in st]
+    ok = bool(torch.stack([torch.isfinite(t).all() for _, t in ts if t.numel()]).all().item())
+    if not ok and report is not None:        # which tensors, how many rows, and the first offending Gaussian
+        for n, t in ts:
+            bad = ~torch.isfinite(t.reshape(t.shape[0], -1)).all(1)
+            if bool(bad.any()):
+                i = int(torch.nonzero(bad)[0])
+                report(f"    non-finite: {n}: {int(bad.sum())} rows, first Gaussian {i}: xyz {model._xyz[i].tolist()} scaling "
+                       f"{model._scaling[i].tolist()} opacity {model._opacity[i].tolist()} rotation {model._rotation[i].tolist()}")
+    return ok
 
 
 def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=None, quiet=False, model_out=None,
-        start_fraction=1.0, grad_threshold=None):
+        start_fraction=1.0, grad_threshold=None, watch_from=None):
     """-> summary dict.  `schedule_iterations`: opt.iterations (the lr schedule's horizon and the one iteration that
     takes no optimiser step); default = `iterations`, i.e. the run IS the whole schedule."""
     dev = torch.device("cuda:0")
@@ -97,12 +107,57 @@ def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=
     t0 = time.time()
     tl = [t0, 0]
 
+    prev = {}
+
+    def watch(it):
+        """Diagnostic (--watch-from): after every iteration from `watch_from`, look for the first non-finite parameter row
+        and print that Gaussian's parameters and Adam moments as they were ONE iteration earlier and as they are now."""
+        vp.finish()
+        torch.cuda.synchronize()
+        names = ["xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation"]
+        cur = {}
+        for nm, p in zip(names, m.parameters()):
+            st = m.optimizer.state.get(p, {})
+            cur[nm] = p.detach().clone()
+            for k in ("exp_avg", "exp_avg_sq"):
+                if k in st:
+                    cur[f"{nm}.{k}"] = st[k].clone()
+        bad = torch.zeros(cur["xyz"].shape[0], dtype=torch.bool, device=dev)
+        for nm, t in cur.items():
+            bad |= ~torch.isfinite(t.reshape(t.shape[0], -1)).all(1)
+        if bool(bad.any()) and prev:
+            i = int(torch.nonzero(bad)[0])
+            print(f"[watch] first non-finite row after iteration {it}: Gaussian {i} ({int(bad.sum())} rows in all)", flush=True)
+            for nm in cur:
+                if nm.startswith("features_rest"):
+                    continue
+                print(f"   {nm:22s} before {prev[nm][i].flatten().tolist()}  after {cur[nm][i].flatten().tolist()}", flush=True)
+            # which view's gradient does it: the plain (non-pipelined) path at the parameters of one iteration earlier
+            from gaussmart_amd.trainer import training_losses
+            probe = GaussianModel(3, device=dev)
+            probe.create_from_params({k: prev[k] for k in names}, active_sh_degree=int(m.active_sh_degree))
+            for ci, c in enumerate(train_cams):
+                for q in probe.parameters():
+                    q.grad = None
+                pkg = render(c, probe, pipe, bg)
+                total, _ = training_losses(pkg, c.original_image, opt, it, c, pipe)
+                total.backward()
+                torch.cuda.synchronize()
+                rows = {nm: q.grad[i].flatten().tolist() for nm, q in zip(names, probe.parameters()) if nm != "features_rest" and q.grad is not None}
+                nonf = {nm: int((~torch.isfinite(q.grad.reshape(q.shape[0], -1)).all(1)).sum()) for nm, q in zip(names, probe.parameters()) if q.grad is not None}
+                print(f"   view {ci}: radius {int(pkg['radii'][i])}  loss {float(total):.5f}  non-finite gradient rows {nonf}  grads of Gaussian {i}: {rows}", flush=True)
+            raise SystemExit(3)
+        prev.clear()
+        prev.update(cur)
+
     def on_iteration(it):
+        if watch_from is not None and it >= watch_from:
+            watch(it)
         if it % log_every == 0 or it in marks:
             vp.finish()
             torch.cuda.synchronize()
             now = time.time()
-            ok = all_finite(m)
+            ok = all_finite(m, report=None if quiet else (lambda msg: print(msg, flush=True)))
             loss = float(last_losses["l"]["loss"]) if "l" in last_losses else float("nan")
             trace.append((it, int(m.get_xyz.shape[0]), round(now - t0, 3), loss, int(m.active_sh_degree), ok))
             if not quiet:
@@ -173,10 +228,12 @@ def main(argv=None):
     ap.add_argument("--extent", type=float, default=5.0, help="cameras_extent handed to densify_and_prune")
     ap.add_argument("--start-fraction", type=float, default=1.0, help="start from every k-th Gaussian of the perturbed scene")
     ap.add_argument("--grad-threshold", type=float, default=None, help="opt.densify_grad_threshold (default: the reference's 0.0002)")
+    ap.add_argument("--watch-from", type=int, default=None, help="diagnostic: from this iteration on, check every iteration and "
+                    "print the first Gaussian that turns non-finite, before and after")
     ap.add_argument("--out", default=None)
     a = ap.parse_args(argv)
     s = run(a.preset, a.iterations, a.views, a.log_every, a.seed, a.extent, a.schedule_iterations,
-            start_fraction=a.start_fraction, grad_threshold=a.grad_threshold)
+            start_fraction=a.start_fraction, grad_threshold=a.grad_threshold, watch_from=a.watch_from)
     line = {k: v for k, v in s.items() if k != "trace"}
     print(json.dumps(line))
     if a.out:
