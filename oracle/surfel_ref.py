@@ -299,16 +299,24 @@ def _tile_eval(px, py, Tm, xy, nrm, opa, rgb, flags, margins=False, flip_tol=Non
     p2 = k0 * l1 - k1 * l0
     valid = p2.detach() != 0
     p2s = torch.where(valid, p2, torch.ones_like(p2))
-    sx, sy = p0 / p2s, p1 / p2s
-    rho3d = sx * sx + sy * sy
+    sx_v, sy_v = p0.detach() / p2s.detach(), p1.detach() / p2s.detach()       # the values (IEEE division, as the reference's)
     dx = xy[:, 0:1] - pxb
     dy = xy[:, 1:2] - pyb
     rho2d = FILTER_INV_SQUARE * (dx * dx + dy * dy)
-    use3d = rho3d.detach() <= rho2d.detach()
+    rho3d_v = sx_v * sx_v + sy_v * sy_v
+    use3d = rho3d_v <= rho2d.detach()
+    # The reference differentiates s = p / p.z only inside its `rho3d <= rho2d` branch.  Autograd through torch.where would
+    # evaluate the quotient's derivative (-p / p.z^2) on the other branch too and multiply it by zero: for a surfel whose
+    # scales collapsed (p.z ~ 1e-33 and below in fp32) that is inf x 0 = NaN in rows the reference leaves finite.  So the
+    # differentiable quotient is formed only where the branch is taken (same values, same gradients there).
+    one, zero = torch.ones_like(p2s), torch.zeros_like(p2s)
+    den = torch.where(use3d, p2s, one)
+    sx, sy = torch.where(use3d, p0, zero) / den, torch.where(use3d, p1, zero) / den
+    rho3d = sx * sx + sy * sy
     rho = torch.where(use3d, rho3d, rho2d)
     z3d = sx * Tw[:, 0:1] + sy * Tw[:, 1:2] + Tw[:, 2:3]
     if flags & QUIRK_FILTER_DEPTH_GRAD:
-        zq = sx.detach() * Tw[:, 0:1] + sy.detach() * Tw[:, 1:2]
+        zq = sx_v * Tw[:, 0:1] + sy_v * Tw[:, 1:2]
         z2d = Tw[:, 2:3] + (zq - zq.detach())
     else:
         z2d = Tw[:, 2:3].expand_as(z3d)
@@ -369,7 +377,7 @@ def _tile_eval(px, py, Tm, xy, nrm, opa, rgb, flags, margins=False, flip_tol=Non
         out["m_alpha"] = torch.where(pre_alpha_valid & live, (a_d - ALPHA_MIN).abs() / ALPHA_MIN, big).amin(0)
         out["m_term"] = torch.where(valid & live, (cum - T_EPS).abs() / T_EPS, big).amin(0)
         out["m_med"] = torch.where(contrib, (T_i.detach() - 0.5).abs(), big).amin(0)
-        out["m_rho"] = torch.where(contrib, (rho3d.detach() - rho2d.detach()).abs()
+        out["m_rho"] = torch.where(contrib, (rho3d_v - rho2d.detach()).abs()
                                    / (rho.detach() + 1e-12), big).amin(0)
     if flip_tol is not None:
         big = torch.full_like(alpha, float("inf")).detach()
@@ -379,7 +387,7 @@ def _tile_eval(px, py, Tm, xy, nrm, opa, rgb, flags, margins=False, flip_tol=Non
         pair_m = torch.where(near_alpha, (a_d - ALPHA_MIN).abs() / ALPHA_MIN, big)
         pair_m = torch.minimum(pair_m, torch.where(valid & live, (cum - T_EPS).abs() / T_EPS, big))
         pair_m = torch.minimum(pair_m, torch.where(contrib, (T_i.detach() - 0.5).abs(), big))
-        pair_m = torch.minimum(pair_m, torch.where(contrib, (rho3d.detach() - rho2d.detach()).abs()
+        pair_m = torch.minimum(pair_m, torch.where(contrib, (rho3d_v - rho2d.detach()).abs()
                                                    / (rho.detach() + 1e-12), big))
         pair_m = torch.minimum(pair_m, torch.where(contrib, (araw_d - ALPHA_MAX).abs() / ALPHA_MAX, big))
         pair_m = torch.minimum(pair_m, torch.where(live & (p2.detach() != 0) & (a_d >= ALPHA_MIN * (1 - flip_tol)),

@@ -59,15 +59,25 @@ def all_finite(model, report=None):
 
 
 def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=None, quiet=False, model_out=None,
-        start_fraction=1.0, grad_threshold=None, watch_from=None):
+        start_fraction=1.0, grad_threshold=None, watch_from=None,
+        lambda_normal=None, lambda_dist=None, depth_ratio=None, white_background=False):
     """-> summary dict.  `schedule_iterations`: opt.iterations (the lr schedule's horizon and the one iteration that
     takes no optimiser step); default = `iterations`, i.e. the run IS the whole schedule."""
     dev = torch.device("cuda:0")
     n, w, h, radius = PRESETS[preset]
     params, _ = make_scene(n, w, h, seed=seed, radius_px=radius)
     cams = jittered_cameras(views + 2, w, h, seed=seed, device=dev, amount=0.3)
-    pipe, opt, bg = PipelineParams(), OptimizationParams(), torch.zeros(3, device=dev)
+    pipe, opt = PipelineParams(), OptimizationParams()
+    bg = torch.ones(3, device=dev) if white_background else torch.zeros(3, device=dev)
     opt.iterations = int(schedule_iterations or iterations)
+    # the reference's other documented settings (README: --lambda_dist 100 / 1000, --depth_ratio 1 for bounded scenes;
+    # scripts/dtu_eval.py:45 trains with lambda_normal = lambda_dist = 0)
+    if lambda_normal is not None:
+        opt.lambda_normal = float(lambda_normal)
+    if lambda_dist is not None:
+        opt.lambda_dist = float(lambda_dist)
+    if depth_ratio is not None:
+        pipe.depth_ratio = float(depth_ratio)
     if grad_threshold is not None:
         opt.densify_grad_threshold = float(grad_threshold)
     target = GaussianModel(3, device=dev)
@@ -180,7 +190,7 @@ def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=
     T.training_step = step_and_remember
     try:
         train(m, train_cams, opt, pipe, bg, cameras_extent=extent, first_iter=0, iterations=iterations,
-              view_parallel=vp, seed=seed, state=state, on_iteration=on_iteration)
+              view_parallel=vp, seed=seed, state=state, on_iteration=on_iteration, white_background=white_background)
     finally:
         T.training_step = orig_step
     torch.cuda.synchronize()
@@ -190,7 +200,8 @@ def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=
     dens_s = phase_t.get(dens_end, total_s)
     summary = {
         "preset": preset, "start_points": int(start["xyz"].shape[0]), "target_points": n, "densify_grad_threshold": opt.densify_grad_threshold,
-        "width": w, "height": h, "radius_px": radius, "views": views,
+        "width": w, "height": h, "radius_px": radius, "views": views, "lambda_normal": opt.lambda_normal, "lambda_dist": opt.lambda_dist,
+        "depth_ratio": pipe.depth_ratio, "white_background": bool(white_background),
         "iterations": iterations, "schedule_iterations": opt.iterations, "cameras_extent": extent, "seed": seed,
         "densification_phase": {"iterations": dens_end, "seconds": round(dens_s, 2),
                                 "it_per_s": round(dens_end / dens_s, 1)},
@@ -228,12 +239,17 @@ def main(argv=None):
     ap.add_argument("--extent", type=float, default=5.0, help="cameras_extent handed to densify_and_prune")
     ap.add_argument("--start-fraction", type=float, default=1.0, help="start from every k-th Gaussian of the perturbed scene")
     ap.add_argument("--grad-threshold", type=float, default=None, help="opt.densify_grad_threshold (default: the reference's 0.0002)")
+    ap.add_argument("--lambda-normal", type=float, default=None)
+    ap.add_argument("--lambda-dist", type=float, default=None)
+    ap.add_argument("--depth-ratio", type=float, default=None)
+    ap.add_argument("--white-background", action="store_true")
     ap.add_argument("--watch-from", type=int, default=None, help="diagnostic: from this iteration on, check every iteration and "
                     "print the first Gaussian that turns non-finite, before and after")
     ap.add_argument("--out", default=None)
     a = ap.parse_args(argv)
     s = run(a.preset, a.iterations, a.views, a.log_every, a.seed, a.extent, a.schedule_iterations,
-            start_fraction=a.start_fraction, grad_threshold=a.grad_threshold, watch_from=a.watch_from)
+            start_fraction=a.start_fraction, grad_threshold=a.grad_threshold, watch_from=a.watch_from,
+            lambda_normal=a.lambda_normal, lambda_dist=a.lambda_dist, depth_ratio=a.depth_ratio, white_background=a.white_background)
     line = {k: v for k, v in s.items() if k != "trace"}
     print(json.dumps(line))
     if a.out:
