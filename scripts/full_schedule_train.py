@@ -12,6 +12,10 @@ cameras gives the ground-truth images, the trained model starts from a perturbed
 Prints one line per `--log-every` iterations (iteration, N, it/s since the last line, loss, peak memory) and writes a
 JSON summary: it/s of the densification phase and of the rest SEPARATELY, N over time, PSNR before / after (training
 views and two held-out views), peak HBM, and whether any parameter or Adam moment ever was non-finite.
+
+Under torch.distributed.run (WORLD_SIZE > 1) the same schedule runs view-parallel: each rank renders its shard of every
+epoch's shuffle, gradients and densification statistics are exchanged, and every log point also checks that
+the replicas are BIT-identical.  GSR_BENCH_BACKEND=gloo GSR_BENCH_SINGLE_DEVICE=1 puts all ranks on one GPU (rehearsal).
 """
 import argparse
 import json
@@ -63,7 +67,13 @@ def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=
         lambda_normal=None, lambda_dist=None, depth_ratio=None, white_background=False):
     """-> summary dict.  `schedule_iterations`: opt.iterations (the lr schedule's horizon and the one iteration that
     takes no optimiser step); default = `iterations`, i.e. the run IS the whole schedule."""
-    dev = torch.device("cuda:0")
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    single = os.environ.get("GSR_BENCH_SINGLE_DEVICE", "0") == "1"
+    dev = torch.device("cuda:0" if (world == 1 or single) else f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+    torch.cuda.set_device(dev)
+    if world > 1 and not torch.distributed.is_initialized():
+        torch.distributed.init_process_group(os.environ.get("GSR_BENCH_BACKEND", "nccl"))
+    quiet = quiet or rank != 0
     n, w, h, radius = PRESETS[preset]
     params, _ = make_scene(n, w, h, seed=seed, radius_px=radius)
     cams = jittered_cameras(views + 2, w, h, seed=seed, device=dev, amount=0.3)
@@ -107,6 +117,7 @@ def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=
                                            c.original_image[None]).mean() for c in cs]).mean())
 
     before = (mean_psnr(train_cams), mean_psnr(held_out))
+    replicas = []         # per log point: are the ranks' parameters bit-identical (always True on one rank)
     trace = []            # (iteration, N, seconds since start, loss, SH degree, finite)
     phase_t = {}          # iteration -> wall seconds at that point (synchronised)
     marks = sorted({min(opt.densify_until_iter, iterations), iterations})
@@ -168,12 +179,14 @@ def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=
             torch.cuda.synchronize()
             now = time.time()
             ok = all_finite(m, report=None if quiet else (lambda msg: print(msg, flush=True)))
+            same = vp.replicas_identical()           # (every rank calls it: a collective)
+            replicas.append(bool(same))
             loss = float(last_losses["l"]["loss"]) if "l" in last_losses else float("nan")
             trace.append((it, int(m.get_xyz.shape[0]), round(now - t0, 3), loss, int(m.active_sh_degree), ok))
             if not quiet:
                 print(f"[it {it:6d}] N {m.get_xyz.shape[0]:8d}  sh {m.active_sh_degree}  "
                       f"{(it - tl[1]) / max(now - tl[0], 1e-9):7.1f} it/s  peak {torch.cuda.max_memory_allocated() / 2**30:5.1f} GiB"
-                      f"  finite {ok}", flush=True)
+                      f"  finite {ok}" + (f"  replicas identical {same}" if world > 1 else ""), flush=True)
             tl[0], tl[1] = time.time(), it
             if it in marks:
                 phase_t[it] = now - t0
@@ -218,6 +231,8 @@ def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=
         "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2),
         "reserved_hbm_gib": round(torch.cuda.max_memory_reserved() / 2**30, 2),
         "all_finite_at_every_log_point": all(t[5] for t in trace),
+        "world_size": world, "backend": (torch.distributed.get_backend() if world > 1 else None),
+        "replicas_identical_at_every_log_point": all(replicas),
         "row_scans_carried": R.STATS["row_scans_carried"],
         "trace_columns": ["iteration", "points", "seconds", "loss", "sh_degree", "finite"],
         "trace": trace,
@@ -251,12 +266,14 @@ def main(argv=None):
             start_fraction=a.start_fraction, grad_threshold=a.grad_threshold, watch_from=a.watch_from,
             lambda_normal=a.lambda_normal, lambda_dist=a.lambda_dist, depth_ratio=a.depth_ratio, white_background=a.white_background)
     line = {k: v for k, v in s.items() if k != "trace"}
-    print(json.dumps(line))
-    if a.out:
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps(line))
+    if a.out and int(os.environ.get("RANK", "0")) == 0:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
         with open(a.out, "w") as f:
             json.dump(s, f, indent=1)
     assert s["all_finite_at_every_log_point"], "non-finite parameter or moment"
+    assert s["replicas_identical_at_every_log_point"], "the replicas of a view-parallel run diverged"
     assert math.isfinite(s["psnr_train_before_after_db"][1])
 
 
