@@ -26,6 +26,10 @@ class PipelineParams:
     # not in the reference: while no regularizer is active the fused trainer asks the forward for the colour image alone
     # (GSR_FLAG_COLOR_ONLY: allmap neither accumulated nor written; the reference computes it and multiplies it by zero)
     color_only_when_unregularized: bool = True
+    # not in the reference: on a HIP device the trainer applies the objective as one fused autograd node on allmap; True keeps
+    # the reference's own formulation instead (render() derives the maps in torch, utils/loss_utils.py's L1 + SSIM, the two
+    # regularizers as train.py:132-143) -- what a PYTHONPATH swap under the reference's train.py runs
+    reference_objective: bool = False
 
 
 @dataclass

@@ -56,7 +56,11 @@ def training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam=None, pi
                                           lambda_normal, lambda_dist, pipe.depth_ratio, defer_value=defer_value)
         l1, ssim_v = parts[0], parts[1]
         return total, {"l1": l1, "ssim": ssim_v, "normal_mean": parts[2], "dist_mean": parts[3], "loss": total.detach()}
-    loss, Ll1 = photometric(image, gt_image, opt.lambda_dssim)
+    if image.is_cuda and getattr(pipe, "reference_objective", False):      # utils/loss_utils.py's torch L1 + SSIM, on the device
+        Ll1 = l1_loss(image, gt_image)
+        loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim(image, gt_image))
+    else:
+        loss, Ll1 = photometric(image, gt_image, opt.lambda_dssim)
     normal_error = (1 - (render_pkg["rend_normal"] * render_pkg["surf_normal"]).sum(dim=0))[None]
     normal_loss = lambda_normal * normal_error.mean()
     dist_loss = lambda_dist * render_pkg["rend_dist"].mean()
@@ -109,7 +113,8 @@ def training_step(gaussians, viewpoint_cam, gt_image, opt, pipe, background, ite
         render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=False, factored_sh_grad=True,
                                color_only=no_reg and lean, no_dist_median=no_dm and lean)
     else:
-        render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background, surface_maps=not on_device)
+        render_pkg = render_fn(viewpoint_cam, gaussians, pipe, background,
+                               surface_maps=(not on_device) or bool(getattr(pipe, "reference_objective", False)))
     # (the backward follows at once: the loss scalars are written by a workgroup of its first kernel, not by a launch of
     # their own -- nobody reads them before this function returns)
     total, parts = training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam, pipe, defer_value=True)

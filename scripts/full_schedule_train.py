@@ -64,7 +64,7 @@ def all_finite(model, report=None):
 
 def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=None, quiet=False, model_out=None,
         start_fraction=1.0, grad_threshold=None, watch_from=None,
-        lambda_normal=None, lambda_dist=None, depth_ratio=None, white_background=False):
+        lambda_normal=None, lambda_dist=None, depth_ratio=None, white_background=False, mode="fused"):
     """-> summary dict.  `schedule_iterations`: opt.iterations (the lr schedule's horizon and the one iteration that
     takes no optimiser step); default = `iterations`, i.e. the run IS the whole schedule."""
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -88,6 +88,13 @@ def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=
         opt.lambda_dist = float(lambda_dist)
     if depth_ratio is not None:
         pipe.depth_ratio = float(depth_ratio)
+    dropin = mode == "dropin"
+    if dropin:
+        # what a PYTHONPATH swap under the reference's train.py runs (bench.py --mode dropin): the
+        # reference-signature operator behind torch activations, render()'s torch post-processing, torch L1 + SSIM and the
+        # regularizers as train.py:132-143, torch.optim.Adam over the six parameter groups
+        pipe.fused_activations = pipe.factored_sh_grad = False
+        pipe.reference_objective = True
     if grad_threshold is not None:
         opt.densify_grad_threshold = float(grad_threshold)
     target = GaussianModel(3, device=dev)
@@ -107,8 +114,10 @@ def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=
         start = {name: t[::k].contiguous() for name, t in start.items()}
         start["scaling"] = start["scaling"] + 0.5 * math.log(k)
     m.create_from_params(start, active_sh_degree=0)
+    if dropin:
+        m.use_fused_adam = False
     m.training_setup(opt)
-    vp = ViewParallel(m, overlap_local=True)
+    vp = ViewParallel(m, overlap_local=not dropin)
 
     def mean_psnr(cs):
         with torch.no_grad():
@@ -203,7 +212,8 @@ def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=
     T.training_step = step_and_remember
     try:
         train(m, train_cams, opt, pipe, bg, cameras_extent=extent, first_iter=0, iterations=iterations,
-              view_parallel=vp, seed=seed, state=state, on_iteration=on_iteration, white_background=white_background)
+              view_parallel=None if dropin else vp, seed=seed, state=state, on_iteration=on_iteration,
+              white_background=white_background)
     finally:
         T.training_step = orig_step
     torch.cuda.synchronize()
@@ -212,7 +222,7 @@ def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=
     dens_end = min(opt.densify_until_iter, iterations)
     dens_s = phase_t.get(dens_end, total_s)
     summary = {
-        "preset": preset, "start_points": int(start["xyz"].shape[0]), "target_points": n, "densify_grad_threshold": opt.densify_grad_threshold,
+        "mode": mode, "preset": preset, "start_points": int(start["xyz"].shape[0]), "target_points": n, "densify_grad_threshold": opt.densify_grad_threshold,
         "width": w, "height": h, "radius_px": radius, "views": views, "lambda_normal": opt.lambda_normal, "lambda_dist": opt.lambda_dist,
         "depth_ratio": pipe.depth_ratio, "white_background": bool(white_background),
         "iterations": iterations, "schedule_iterations": opt.iterations, "cameras_extent": extent, "seed": seed,
@@ -254,6 +264,8 @@ def main(argv=None):
     ap.add_argument("--extent", type=float, default=5.0, help="cameras_extent handed to densify_and_prune")
     ap.add_argument("--start-fraction", type=float, default=1.0, help="start from every k-th Gaussian of the perturbed scene")
     ap.add_argument("--grad-threshold", type=float, default=None, help="opt.densify_grad_threshold (default: the reference's 0.0002)")
+    ap.add_argument("--mode", choices=("fused", "dropin"), default="fused", help="dropin: the reference-shaped loop around the "
+                    "reference-signature operator (torch activations / post-processing / L1 + SSIM / Adam)")
     ap.add_argument("--lambda-normal", type=float, default=None)
     ap.add_argument("--lambda-dist", type=float, default=None)
     ap.add_argument("--depth-ratio", type=float, default=None)
@@ -264,7 +276,7 @@ def main(argv=None):
     a = ap.parse_args(argv)
     s = run(a.preset, a.iterations, a.views, a.log_every, a.seed, a.extent, a.schedule_iterations,
             start_fraction=a.start_fraction, grad_threshold=a.grad_threshold, watch_from=a.watch_from,
-            lambda_normal=a.lambda_normal, lambda_dist=a.lambda_dist, depth_ratio=a.depth_ratio, white_background=a.white_background)
+            lambda_normal=a.lambda_normal, lambda_dist=a.lambda_dist, depth_ratio=a.depth_ratio, white_background=a.white_background, mode=a.mode)
     line = {k: v for k, v in s.items() if k != "trace"}
     if int(os.environ.get("RANK", "0")) == 0:
         print(json.dumps(line))
