@@ -300,6 +300,9 @@ def main():
     ap.add_argument("--cpu-gaussians", type=int, default=250_000)
     ap.add_argument("--cpu-full", action="store_true", help="CPU baseline on the whole frame, un-sampled (~2 min)")
     ap.add_argument("--forward-frames", type=int, default=50, help="inference frames (no_grad render) timed after the run")
+    ap.add_argument("--dropin-loss", choices=("torch", "hip"), default="torch",
+                    help="--mode dropin: `torch` = the reference's utils/loss_utils.py formulation (five grouped convolutions through "
+                         "MIOpen); `hip` = gaussmart_amd.loss_utils, the same two functions on the fused kernel")
     ap.add_argument("--mode", choices=("fused", "dropin"), default="fused",
                     help="fused (default, the headline): the build's own trainer -- raw-parameter operator, fused objective, "
                          "factored SH Adam.  dropin: what INTEGRATION.md section 1 delivers under the reference's own loop -- "
@@ -419,7 +422,10 @@ def main():
         # One iteration of the reference's loop (train.py:93-216) around the drop-in operator: render() with torch
         # activations and the torch post-processing (expected depth, depth_to_normal, ...), torch L1 + SSIM, the two
         # regularizers, backward, one .item() (the reference reads four for its progress bar), torch Adam.
-        from gaussmart_amd.losses import l1_loss, ssim
+        if args.dropin_loss == "hip":       # the one-line swap of INTEGRATION.md section 1: same names, the fused kernel underneath
+            from gaussmart_amd.loss_utils import l1_loss, ssim
+        else:
+            from gaussmart_amd.losses import l1_loss, ssim
         ema = [0.0]
 
         def step(i):        # noqa: F811
@@ -627,7 +633,9 @@ def main():
                        "entries_walked_per_pixel_max": int(nc.max()),
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",
                        "mode": args.mode + (" (reference-signature operator under a reference-shaped loop: torch activations, "
-                                            "torch post-processing + L1 + SSIM, torch.optim.Adam, one .item() per step)"
+                                            "torch post-processing, " + ("gaussmart_amd.loss_utils l1_loss / ssim (HIP)" if args.dropin_loss == "hip"
+                                                                        else "torch L1 + SSIM") +
+                                            ", torch.optim.Adam, one .item() per step)"
                                             if dropin else " (raw-parameter operator, fused objective, factored SH Adam)"),
                        "loss": "L1 + SSIM only (--eval-flags: lambda_normal 0, lambda_dist 0, scripts/dtu_eval.py:45)"
                                if args.eval_flags else "L1 + SSIM + normal consistency (lambda_normal 0.05, lambda_dist 0)",
