@@ -300,6 +300,9 @@ def main():
     ap.add_argument("--cpu-gaussians", type=int, default=250_000)
     ap.add_argument("--cpu-full", action="store_true", help="CPU baseline on the whole frame, un-sampled (~2 min)")
     ap.add_argument("--forward-frames", type=int, default=50, help="inference frames (no_grad render) timed after the run")
+    ap.add_argument("--dropin-adam", choices=("torch", "hip"), default="torch",
+                    help="--mode dropin: `torch` = torch.optim.Adam as scene/gaussian_model.py:295 builds it; `hip` = "
+                         "gaussmart_amd.fused_adam.FusedAdam (same class interface and state, one launch per step)")
     ap.add_argument("--dropin-loss", choices=("torch", "hip"), default="torch",
                     help="--mode dropin: `torch` = the reference's utils/loss_utils.py formulation (five grouped convolutions through "
                          "MIOpen); `hip` = gaussmart_amd.loss_utils, the same two functions on the fused kernel")
@@ -390,7 +393,9 @@ def main():
     model = GaussianModel(3, device=dev)
     model.create_from_params(params)
     if dropin:
-        model.use_fused_adam = False       # torch.optim.Adam over the six parameter groups (scene/gaussian_model.py:282-295)
+        # torch.optim.Adam over the six parameter groups (scene/gaussian_model.py:282-295); --dropin-adam hip: the second optional
+        # one-line swap of INTEGRATION.md section 1 (fused_adam.FusedAdam: a torch.optim.Adam subclass, same state layout)
+        model.use_fused_adam = args.dropin_adam == "hip"
     model.training_setup(opt)
     force_dp = bool(os.environ.get("GSR_BENCH_FORCE_DP")) and dist.is_initialized()   # rehearsal on one GPU
     vp = ViewParallel(model, force=force_dp) if (world > 1 or force_dp) else None
@@ -635,7 +640,7 @@ def main():
                        "mode": args.mode + (" (reference-signature operator under a reference-shaped loop: torch activations, "
                                             "torch post-processing, " + ("gaussmart_amd.loss_utils l1_loss / ssim (HIP)" if args.dropin_loss == "hip"
                                                                         else "torch L1 + SSIM") +
-                                            ", torch.optim.Adam, one .item() per step)"
+                                            ", " + ("fused_adam.FusedAdam" if args.dropin_adam == "hip" else "torch.optim.Adam") + ", one .item() per step)"
                                             if dropin else " (raw-parameter operator, fused objective, factored SH Adam)"),
                        "loss": "L1 + SSIM only (--eval-flags: lambda_normal 0, lambda_dist 0, scripts/dtu_eval.py:45)"
                                if args.eval_flags else "L1 + SSIM + normal consistency (lambda_normal 0.05, lambda_dist 0)",
