@@ -129,3 +129,49 @@ def test_schedule_script_presets_match_bench():
     for name in ("scan24", "bicycle", "headline"):
         p = bench.PRESETS[name]
         assert FS.PRESETS[name] == (p["gaussians"], p["width"], p["height"], p["radius_px"])
+
+
+def test_loss_utils_refuses_what_it_does_not_implement():
+    """gaussmart_amd.loss_utils (the reference's l1_loss / ssim signatures on the fused kernel): argument checks run before any
+    device work, and a CPU tensor is refused -- there is no CPU path behind these names."""
+    from gaussmart_amd import _lib, loss_utils as H
+    a, b = torch.rand(3, 16, 16, requires_grad=True), torch.rand(3, 16, 16)
+    with pytest.raises(ValueError):
+        H.ssim(a, b, window_size=7)
+    with pytest.raises(ValueError):
+        H.ssim(a, b, size_average=False)
+    with pytest.raises(ValueError):
+        H.l1_loss(a, b.clone().requires_grad_(True))
+    with pytest.raises(ValueError):
+        H.l1_loss(a, b[:, :8])
+    with pytest.raises(ValueError):
+        H.ssim(torch.rand(2, 3, 16, 16), torch.rand(2, 3, 16, 16))      # a batch: the kernel takes one image
+    with pytest.raises(_lib.GsrError):
+        H.l1_loss(a, b)
+    with pytest.raises(_lib.GsrError):
+        H.ssim(a[None], b[None])
+
+
+def test_reference_objective_switch_keeps_the_torch_maps(monkeypatch):
+    """PipelineParams.reference_objective: training_step asks render() for the torch-derived maps (surface_maps=True), i.e. the
+    reference's own objective formulation, instead of the fused node on allmap."""
+    import gaussmart_amd.trainer as T
+    from gaussmart_amd.params import OptimizationParams, PipelineParams
+    seen = []
+
+    class Stop(Exception):
+        pass
+
+    def fake_render(cam, g, pipe, bg, **kw):
+        seen.append(kw.get("surface_maps"))
+        raise Stop
+
+    g = types.SimpleNamespace(update_learning_rate=lambda it: None, get_xyz=types.SimpleNamespace(is_cuda=True), optimizer=None,
+                              active_sh_degree=3)
+    for flag in (False, True):
+        opt, pipe = OptimizationParams(), PipelineParams()
+        pipe.reference_objective = flag
+        pipe.factored_sh_grad = False
+        with pytest.raises(Stop):
+            T.training_step(g, None, None, opt, pipe, None, 8000, render_fn=fake_render)
+    assert seen == [False, True]
