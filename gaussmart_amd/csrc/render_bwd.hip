@@ -301,7 +301,10 @@ __global__ void __launch_bounds__(RB_BLOCK, NOSURF ? 8 : RB_MIN_WAVES) render_bw
                     const float dL_dsx = NOSURF ? dL_dG * (-G * sx) : dL_dG * (-G * sx) + dL_dz * Twx;
                     const float dL_dsy = NOSURF ? dL_dG * (-G * sy) : dL_dG * (-G * sy) + dL_dz * Twy;
                     float dpx = dL_dsx * inv_pz, dpy = dL_dsy * inv_pz;
-                    if (pr.tiny_any) { const float zs = pr.tiny ? GSR_TINY_PZ_SCALE : 1.f; dpx *= zs; dpy *= zs; }   // (pair_eval.h: a denormal p.z)
+                    if (__builtin_expect(pr.tiny_any, 0)) {       // (pair_eval.h: a denormal p.z; the empty asm keeps this a BRANCH -- if-converted it cost
+                        asm volatile("");                         //  three vector instructions on every pair, +3.7 % of K7's issue)
+                        const float zs = pr.tiny ? GSR_TINY_PZ_SCALE : 1.f; dpx *= zs; dpy *= zs;
+                    }
                     const float dpz = -(dpx * sx + dpy * sy);
                     // dL/dTu = -dL/dk = dL/dp x l ;  dL/dTv = -dL/dl = k x dL/dp
                     const float ux = dpy * pr.lz - dpz * pr.ly, uy = dpz * pr.lx - dpx * pr.lz, uz = dpx * pr.ly - dpy * pr.lx;
