@@ -7,7 +7,7 @@
 Same names, same argument meaning (utils/loss_utils.py:16-17 and :42-57), same values; each call is ONE launch of the fused
 photometric kernel each way (csrc/loss.hip) instead of the five grouped convolutions `ssim` costs through MIOpen -- at 1080p
 that torch formulation alone is 61 % of an iteration of the reference's loop around the drop-in operator
-(profiles/r04_v3_dropin_kernel_stats.csv).  The swap is one line in train.py:
+(profiles/r04_v4_dropin_kernel_stats.csv).  The swap is one line in train.py:
 
     from gaussmart_amd.loss_utils import l1_loss, ssim
 
