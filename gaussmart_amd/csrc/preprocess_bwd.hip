@@ -278,7 +278,8 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
                 dmean[r] = dT[2] * m0 + dT[5] * m1 + dT[8] * m2;
             }
             float qw = p.rots[4 * idx + 0], qx = p.rots[4 * idx + 1], qy = p.rots[4 * idx + 2], qz = p.rots[4 * idx + 3];
-            const float s = rsqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+            const float qn2 = qw * qw + qx * qx + qy * qy + qz * qz;
+            const float s = rsqrtf(qn2);
             qw *= s; qx *= s; qy *= s; qz *= s;
             const float r00 = 1.f - 2.f * (qy * qy + qz * qz), r10 = 2.f * (qx * qy + qw * qz), r20 = 2.f * (qx * qz - qw * qy);
             const float r01 = 2.f * (qx * qy - qw * qz), r11 = 1.f - 2.f * (qx * qx + qz * qz), r21 = 2.f * (qy * qz + qw * qx);
@@ -316,9 +317,14 @@ __global__ void __launch_bounds__(PB_BLOCK) preprocess_bwd_kernel(PreBwdParams p
             if (p.raw) {
                 // through the activations: exp for the scales, normalize for the quaternion
                 dscale0 *= sx / p.mod; dscale1 *= sy / p.mod;      // d exp(x)/dx = exp(x)
-                const float qd = qw * gr + qx * gx + qy * gy + qz * gz;
-                dq[0] = (gr - qw * qd) * s; dq[1] = (gx - qx * qd) * s;
-                dq[2] = (gy - qy * qd) * s; dq[3] = (gz - qz * qd) * s;
+                // torch.nn.functional.normalize divides by max(|q|, 1e-12) (scene/gaussian_model.py:109): below that norm the
+                // activation is a plain scaling, its derivative has no projection, and the operator's own (detached)
+                // normalisation supplies the rest of 1 / |q| -- the row above is already that gradient
+                if (!(qn2 < 1e-24f)) {
+                    const float qd = qw * gr + qx * gx + qy * gy + qz * gz;
+                    dq[0] = (gr - qw * qd) * s; dq[1] = (gx - qx * qd) * s;
+                    dq[2] = (gy - qy * qd) * s; dq[3] = (gz - qz * qd) * s;
+                }
             }
         }
     }

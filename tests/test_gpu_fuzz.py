@@ -130,6 +130,9 @@ def test_random_configuration_against_the_oracle(gpu_device, seed):
     # gradients: per-row error relative to the tensor's scale; median and p90 beside the fp32 oracle
     for k in gh:
         ref = go[k].reshape(n, -1)
+        if ref.numel() == 0:            # (features_rest [N,0,3]: only the dc coefficient is stored)
+            assert gh[k].numel() == 0
+            continue
         tsc = float(ref.abs().max())
         if tsc == 0.0:
             assert float(gh[k].abs().max()) == 0.0, (line, k)
@@ -139,7 +142,125 @@ def test_random_configuration_against_the_oracle(gpu_device, seed):
         mh, m32 = float(eh.median()), float(e32.median())
         ph, p32 = (float(eh.quantile(0.9)), float(e32.quantile(0.9))) if n > 1 else (float(eh.max()), float(e32.max()))
         line += f" | {k} med {mh:.1e}/{m32:.1e} p90 {ph:.1e}/{p32:.1e} max {float(eh.max()):.1e}/{float(e32.max()):.1e}"
-        assert mh <= max(4 * m32, 1e-5), (line, k)
+        assert mh <= max(4 * m32, 1e-5 if n >= 16 else 1e-4), (line, k)      # (a median over a handful of rows is one row)
+        assert ph <= max(4 * p32, 2e-4), (line, k)
+        assert float(eh.max()) <= max(4 * float(e32.max()), 2e-2), (line, k)
+    print("\n   " + line)
+
+
+# ---- the raw-parameter operator (what the fused trainer calls): logits / log-scales / un-normalised quaternions / split SH in,
+# ---- activations inside K1 / K8, and its two lean variants ------------------------------------------------------------------
+RAW_NAMES = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")
+
+
+def build_raw(cfg):
+    from gaussmart_amd.synthetic import jittered_cameras, make_scene
+    p, cam = make_scene(cfg["n"], cfg["w"], cfg["h"], seed=cfg["seed"], radius_px=cfg["radius"])
+    if cfg["view"]:
+        cam = jittered_cameras(cfg["view"] + 1, cfg["w"], cfg["h"], seed=11, amount=0.25)[cfg["view"]]
+    n = cfg["n"]
+    g = torch.Generator().manual_seed(9500 + cfg["seed"])
+    p["rotation"] = p["rotation"] * torch.exp(2.0 * torch.randn(n, 1, generator=g))          # norms from 0.02 to 50
+    if cfg["extreme"] and n >= 5:
+        idx = torch.randperm(n, generator=g)[: max(1, n // 4)]
+        for j, i in enumerate(idx.tolist()):
+            kind = j % 4
+            if kind == 0:
+                p["scaling"][i] = -10 - 45 * torch.rand(2, generator=g)
+            elif kind == 1:
+                p["scaling"][i] = 2.5 * torch.rand(2, generator=g)
+            elif kind == 2:
+                p["opacity"][i] = 16.0 if float(torch.rand(1, generator=g)) < 0.5 else -14.0
+            else:
+                p["rotation"][i] = p["rotation"][i] * 1e-12                                  # a quaternion of norm ~1e-12
+    K = (cfg["deg_store"] + 1) ** 2
+    p["features_rest"] = p["features_rest"][:, : K - 1].contiguous()
+    g = torch.Generator().manual_seed(100 + cfg["seed"])
+    wc, wa = torch.randn(3, cfg["h"], cfg["w"], generator=g), torch.randn(7, cfg["h"], cfg["w"], generator=g)
+    return p, cam, wc, wa
+
+
+def oracle_raw(cfg, p, cam, wc, wa, dtype):
+    from oracle import surfel_ref as O
+    S = oracle_settings(cam, cfg["deg"], dtype, cfg["bg"], scale_modifier=cfg["mod"])
+    oin = {k: p[k].clone().to(dtype).requires_grad_(True) for k in RAW_NAMES}
+    m2d = torch.zeros(cfg["n"], 3, dtype=dtype, requires_grad=True)
+    # scene/gaussian_model.py:103-123: exp, normalize, sigmoid, cat(dc, rest)
+    c, r, am = O.rasterize(oin["xyz"], m2d, torch.sigmoid(oin["opacity"]), torch.cat((oin["features_dc"], oin["features_rest"]), 1),
+                           None, torch.exp(oin["scaling"]), torch.nn.functional.normalize(oin["rotation"]), None, settings=S,
+                           flags=cfg["flags"])
+    ((c * wc.to(dtype)).sum() + (am * wa.to(dtype)).sum()).backward()
+    g = {k: oin[k].grad.double() for k in RAW_NAMES}
+    g["means2D"] = m2d.grad.double()
+    return g, c.detach().double(), am.detach().double(), r
+
+
+def hip_raw(cfg, p, cam, wc, wa, dev, variant):
+    from gaussmart_amd.rasterizer import rasterize_gaussians_raw
+    hin = {k: p[k].clone().to(dev).requires_grad_(True) for k in RAW_NAMES}
+    m2d = torch.zeros(cfg["n"], 3, device=dev, requires_grad=True)
+    rs = hip_settings(cam, cfg["deg"], cfg["bg"], dev, scale_modifier=cfg["mod"])
+    c, r, am = rasterize_gaussians_raw(hin["xyz"], m2d, hin["features_dc"], hin["features_rest"], hin["opacity"], hin["scaling"],
+                                       hin["rotation"], rs, flags=cfg["flags"], color_only=variant == "color_only",
+                                       no_dist_median=variant == "no_dist_median")
+    if am is None:
+        c.backward(wc.to(dev))
+    else:
+        torch.autograd.backward([c, am], [wc.to(dev), wa.to(dev)])
+    torch.cuda.synchronize()
+    g = {k: hin[k].grad.cpu().double() for k in RAW_NAMES}
+    g["means2D"] = m2d.grad.cpu().double()
+    return g, c.detach().cpu().double(), None if am is None else am.detach().cpu().double(), r.cpu()
+
+
+@pytest.mark.parametrize("seed", list(range(100, 136)))
+def test_random_configuration_raw_parameter_operator(gpu_device, seed):
+    cfg = draw(seed)
+    cfg["deg_store"] = max(cfg["deg"], (seed // 3) % 4)                      # stored coefficients >= active degree
+    variant = ("all", "no_dist_median", "color_only")[seed % 3]
+    p, cam, wc, wa = build_raw(cfg)
+    if variant == "no_dist_median":
+        wa[5:] = 0                      # the caller's promise: it consumes neither channel
+    elif variant == "color_only":
+        wa[:] = 0
+    n = cfg["n"]
+    gh, ch, amh, rh = hip_raw(cfg, p, cam, wc, wa, gpu_device, variant)
+    g32, c32, am32, r32 = oracle_raw(cfg, p, cam, wc, wa, torch.float32)
+    go, co, amo, ro = oracle_raw(cfg, p, cam, wc, wa, torch.float64)
+    line = f"seed {seed} [{variant}]: {cfg['w']}x{cfg['h']} n {n} deg {cfg['deg']}/{cfg['deg_store']} flags {cfg['flags']} mod {cfg['mod']:.2f}" \
+           f" view {cfg['view']} extreme {cfg['extreme']} visible {int((ro > 0).sum())}"
+    assert bool(torch.isfinite(ch).all()) and all(bool(torch.isfinite(v).all()) for v in gh.values()), line
+    assert all(bool(torch.isfinite(v).all()) for v in g32.values()), ("fp32 oracle", line)
+    assert int((rh != ro).sum()) <= max(int((r32 != ro).sum()) + 1, n // 100), line
+    if variant == "color_only":
+        assert amh is None
+        img_h, img_o, img_32 = ch, co, c32
+    elif variant == "no_dist_median":
+        assert float(amh[5:].abs().max()) == 0.0
+        img_h, img_o, img_32 = torch.cat([ch, amh[:5]]), torch.cat([co, amo[:5]]), torch.cat([c32, am32[:5]])
+    else:
+        img_h, img_o, img_32 = torch.cat([ch, amh]), torch.cat([co, amo]), torch.cat([c32, am32])
+    P = cfg["w"] * cfg["h"]
+    sc = max(float(img_o.abs().max()), 1.0)
+    dh, d32 = (img_h - img_o).abs().amax(0).flatten(), (img_32 - img_o).abs().amax(0).flatten()
+    assert float(dh.median()) <= max(4 * float(d32.median()), 2e-6 * sc), line
+    big = dh > max(4 * float(d32.max()), 2e-3 * sc)
+    assert int(big.sum()) <= max(1, P // 2000), (line, int(big.sum()))
+    for k in gh:
+        ref = go[k].reshape(n, -1)
+        if ref.numel() == 0:            # (features_rest [N,0,3]: only the dc coefficient is stored)
+            assert gh[k].numel() == 0
+            continue
+        tsc = float(ref.abs().max())
+        if tsc == 0.0:
+            assert float(gh[k].abs().max()) == 0.0, (line, k)
+            continue
+        eh = (gh[k].reshape(n, -1) - ref).abs().amax(1) / tsc
+        e32 = (g32[k].reshape(n, -1) - ref).abs().amax(1) / tsc
+        mh, m32 = float(eh.median()), float(e32.median())
+        ph, p32 = (float(eh.quantile(0.9)), float(e32.quantile(0.9))) if n > 1 else (float(eh.max()), float(e32.max()))
+        line += f" | {k} med {mh:.1e}/{m32:.1e} p90 {ph:.1e}/{p32:.1e} max {float(eh.max()):.1e}/{float(e32.max()):.1e}"
+        assert mh <= max(4 * m32, 1e-5 if n >= 16 else 1e-4), (line, k)      # (a median over a handful of rows is one row)
         assert ph <= max(4 * p32, 2e-4), (line, k)
         assert float(eh.max()) <= max(4 * float(e32.max()), 2e-2), (line, k)
     print("\n   " + line)
