@@ -1,4 +1,4 @@
-"""Differential fuzz: 72 deterministic pseudo-random configurations -- image sizes that are no multiple of the 16-pixel tile
+"""Differential fuzz: 132 deterministic pseudo-random configurations (72 + 36 + 24 over the three tests) -- image sizes that are no multiple of the 16-pixel tile
 (down to 1 x 1), 1 ... 600 Gaussians, SH degree 0 ... 3, every combination of the three recalled-behaviour flags, random
 background and scale modifier, jittered views, SH or precomputed colours, a share of extreme Gaussians (tests/test_gpu_degenerate.py's kinds) -- each
 through the operator and the C ABI against the fp64 oracle, with the fp32 oracle beside it as the yardstick of what single
@@ -261,6 +261,82 @@ def test_random_configuration_raw_parameter_operator(gpu_device, seed):
         ph, p32 = (float(eh.quantile(0.9)), float(e32.quantile(0.9))) if n > 1 else (float(eh.max()), float(e32.max()))
         line += f" | {k} med {mh:.1e}/{m32:.1e} p90 {ph:.1e}/{p32:.1e} max {float(eh.max()):.1e}/{float(e32.max()):.1e}"
         assert mh <= max(4 * m32, 1e-5 if n >= 16 else 1e-4), (line, k)      # (a median over a handful of rows is one row)
+        assert ph <= max(4 * p32, 2e-4), (line, k)
+        assert float(eh.max()) <= max(4 * float(e32.max()), 2e-2), (line, k)
+    print("\n   " + line)
+
+
+# ---- wide payloads (colors_precomp [N,C], C = 4 ... 64: the matrix-pipe kernels) and a precomputed T (cov3D_precomp) ---------
+@pytest.mark.parametrize("seed", list(range(200, 224)))
+def test_random_configuration_wide_payload_and_precomputed_transmat(gpu_device, seed):
+    from gaussmart_amd.rasterizer import GaussianRasterizer
+    from oracle import surfel_ref as O
+    dev = gpu_device
+    cfg = draw(seed)
+    cfg["precomp"] = False
+    a, cam, _, wa = build(cfg)
+    n = cfg["n"]
+    g = torch.Generator().manual_seed(400 + seed)
+    C = [4, 8, 12, 16, 20, 32, 48, 64, 3, 3][seed % 10]                       # (3: the RGB kernels, with a precomputed T)
+    a.pop("shs")
+    a["colors_precomp"] = torch.randn(n, C, generator=g)
+    bg = tuple(float(x) for x in torch.rand(C, generator=g))
+    use_T = seed % 3 == 0
+    if use_T:       # T as K1 would build it, in fp64 and rounded once (the reference's compute_cov3D_python alternative)
+        S64 = oracle_settings(cam, 0, torch.float64, bg, scale_modifier=cfg["mod"])
+        geom = O.preprocess(a["means3D"].double(), a["scales"].double(), a["rotations"].double(), a["opacities"].double(), None,
+                            a["colors_precomp"].double(), None, S64)
+        T = torch.tensor([1., 0, 0, 0, 1, 0, 0, 0, 1]).repeat(n, 1)
+        T[geom.vis_idx] = geom.Tm.reshape(-1, 9).float()
+        a["cov3D_precomp"] = T
+        a.pop("scales"); a.pop("rotations")
+    wc = torch.randn(C, cfg["h"], cfg["w"], generator=g)
+    names = [k for k in GRAD_NAMES if a.get(k) is not None]
+
+    def run_oracle(dtype):
+        S = oracle_settings(cam, 0, dtype, bg, scale_modifier=cfg["mod"])
+        oin = {k: a[k].clone().to(dtype).requires_grad_(True) for k in names}
+        m2d = torch.zeros(n, 3, dtype=dtype, requires_grad=True)
+        c, r, am = O.rasterize(oin["means3D"], m2d, oin["opacities"], None, oin["colors_precomp"], oin.get("scales"),
+                               oin.get("rotations"), oin.get("cov3D_precomp"), settings=S, flags=cfg["flags"])
+        ((c * wc.to(dtype)).sum() + (am * wa.to(dtype)).sum()).backward()
+        gr = {k: oin[k].grad.double() for k in names}
+        gr["means2D"] = m2d.grad.double()
+        return gr, torch.cat([c.detach().double(), am.detach().double()]), r
+
+    hin = {k: a[k].clone().to(dev).requires_grad_(True) for k in names}
+    m2d = torch.zeros(n, 3, device=dev, requires_grad=True)
+    rast = GaussianRasterizer(hip_settings(cam, 0, bg, dev, scale_modifier=cfg["mod"]), flags=cfg["flags"])
+    c, r, am = rast(means3D=hin["means3D"], means2D=m2d, colors_precomp=hin["colors_precomp"], opacities=hin["opacities"],
+                    scales=hin.get("scales"), rotations=hin.get("rotations"), cov3D_precomp=hin.get("cov3D_precomp"))
+    torch.autograd.backward([c, am], [wc.to(dev), wa.to(dev)])
+    torch.cuda.synchronize()
+    gh = {k: hin[k].grad.cpu().double() for k in names}
+    gh["means2D"] = m2d.grad.cpu().double()
+    img_h, rh = torch.cat([c.detach(), am.detach()]).cpu().double(), r.cpu()
+    g32, img_32, r32 = run_oracle(torch.float32)
+    go, img_o, ro = run_oracle(torch.float64)
+    line = f"seed {seed}: C {C} precomputed T {use_T} {cfg['w']}x{cfg['h']} n {n} flags {cfg['flags']} mod {cfg['mod']:.2f} view {cfg['view']}" \
+           f" extreme {cfg['extreme']} visible {int((ro > 0).sum())}"
+    assert bool(torch.isfinite(img_h).all()) and all(bool(torch.isfinite(v).all()) for v in gh.values()), line
+    assert int((rh != ro).sum()) <= max(int((r32 != ro).sum()) + 1, n // 100), line
+    P = cfg["w"] * cfg["h"]
+    sc = max(float(img_o.abs().max()), 1.0)
+    dh, d32 = (img_h - img_o).abs().amax(0).flatten(), (img_32 - img_o).abs().amax(0).flatten()
+    assert float(dh.median()) <= max(4 * float(d32.median()), 2e-6 * sc), line
+    assert int((dh > max(4 * float(d32.max()), 2e-3 * sc)).sum()) <= max(1, P // 2000), line
+    for k in gh:
+        ref = go[k].reshape(n, -1)
+        tsc = float(ref.abs().max())
+        if tsc == 0.0:
+            assert float(gh[k].abs().max()) == 0.0, (line, k)
+            continue
+        eh = (gh[k].reshape(n, -1) - ref).abs().amax(1) / tsc
+        e32 = (g32[k].reshape(n, -1) - ref).abs().amax(1) / tsc
+        mh, m32 = float(eh.median()), float(e32.median())
+        ph, p32 = (float(eh.quantile(0.9)), float(e32.quantile(0.9))) if n > 1 else (float(eh.max()), float(e32.max()))
+        line += f" | {k} med {mh:.1e}/{m32:.1e} p90 {ph:.1e}/{p32:.1e} max {float(eh.max()):.1e}/{float(e32.max()):.1e}"
+        assert mh <= max(4 * m32, 1e-5 if n >= 16 else 1e-4), (line, k)
         assert ph <= max(4 * p32, 2e-4), (line, k)
         assert float(eh.max()) <= max(4 * float(e32.max()), 2e-2), (line, k)
     print("\n   " + line)
