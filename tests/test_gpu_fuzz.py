@@ -1,4 +1,4 @@
-"""Differential fuzz: 132 deterministic pseudo-random configurations (72 + 36 + 24 over the three tests) -- image sizes that are no multiple of the 16-pixel tile
+"""Differential fuzz: 162 deterministic pseudo-random configurations (72 + 36 + 24 + 30 over the four tests) -- image sizes that are no multiple of the 16-pixel tile
 (down to 1 x 1), 1 ... 600 Gaussians, SH degree 0 ... 3, every combination of the three recalled-behaviour flags, random
 background and scale modifier, jittered views, SH or precomputed colours, a share of extreme Gaussians (tests/test_gpu_degenerate.py's kinds) -- each
 through the operator and the C ABI against the fp64 oracle, with the fp32 oracle beside it as the yardstick of what single
@@ -339,4 +339,70 @@ def test_random_configuration_wide_payload_and_precomputed_transmat(gpu_device, 
         assert mh <= max(4 * m32, 1e-5 if n >= 16 else 1e-4), (line, k)
         assert ph <= max(4 * p32, 2e-4), (line, k)
         assert float(eh.max()) <= max(4 * float(e32.max()), 2e-2), (line, k)
+    print("\n   " + line)
+
+
+# ---- the fused objective (L1 + SSIM + normal consistency + distortion) on drawn image sizes, weights and allmaps with holes ----
+@pytest.mark.parametrize("seed", list(range(300, 330)))
+def test_random_objective_against_the_oracles(gpu_device, seed):
+    from gaussmart_amd.fused_objective import training_objective
+    from gaussmart_amd.synthetic import jittered_cameras
+    from oracle import loss_ref, regularizer_ref as R
+    dev = gpu_device
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    W, H = [(1, 1), (2, 5), (11, 11), (16, 16), (31, 47), (64, 33), (97, 5), (130, 71), (40, 150), (33, 32)][seed % 10]
+    lam = [0.0, 0.2, 0.2, 0.7, 1.0][ri(0, 4)]
+    ln = [0.0, 0.05, 0.05, 1.0][ri(0, 3)]
+    ld = [0.0, 0.0, 100.0, 1000.0][ri(0, 3)]
+    ratio = [0.0, 0.0, 0.5, 1.0][ri(0, 3)]
+    cam = jittered_cameras(3, W, H, seed=seed, device=dev, amount=0.3)[seed % 3]
+    img = torch.rand(3, H, W, generator=g)
+    gt = (img + 0.15 * torch.randn(3, H, W, generator=g)).clamp(0, 1)
+    alpha = torch.rand(1, H, W, generator=g)
+    alpha = torch.where(torch.rand(1, H, W, generator=g) < 0.3, torch.zeros_like(alpha), alpha)       # holes: alpha == 0
+    alpha = torch.where(torch.rand(1, H, W, generator=g) < 0.05, torch.full_like(alpha, 1e-7), alpha)  # nearly empty pixels
+    depth = 0.5 + 19.5 * torch.rand(1, H, W, generator=g)
+    nrm = torch.nn.functional.normalize(torch.randn(3, H, W, generator=g), dim=0) * alpha
+    am = torch.cat([alpha * depth, alpha, nrm, torch.where(alpha > 0, depth * (0.8 + 0.4 * torch.rand(1, H, W, generator=g)),
+                                                           torch.zeros_like(depth)), alpha * torch.rand(1, H, W, generator=g)])
+    outs = []
+    for defer in (False, True):
+        ih, ah = img.to(dev).requires_grad_(True), am.to(dev).requires_grad_(True)
+        total, parts = training_objective(ih, ah, gt.to(dev), cam, lam, ln, ld, ratio, defer_value=defer)
+        total.backward()
+        torch.cuda.synchronize()
+        outs.append((float(total.detach()), parts.detach().cpu().double(), ih.grad.cpu().double(),
+                     None if ah.grad is None else ah.grad.cpu().double()))
+    # the deferred form writes the same five scalars and the same gradients
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert (outs[0][3] is None) == (outs[1][3] is None) and (outs[0][3] is None or torch.equal(outs[0][3], outs[1][3]))
+    tot, parts, gi, ga = outs[0]
+    io, ao = img.double().requires_grad_(True), am.double().requires_grad_(True)
+    lo, l1o, so = loss_ref.photometric_loss(io, gt.double(), lam)
+    ro, nmo, dmo = R.regularizer_loss(ao, cam.world_view_transform.cpu().double(), cam.full_proj_transform.cpu().double(), ratio, ln, ld)
+    (lo + ro).backward()
+    use_reg = ln > 0 or ld > 0
+    want = float(lo + ro) if use_reg else float(lo)
+    line = f"seed {seed}: {W}x{H} lambda_dssim {lam} lambda_normal {ln} lambda_dist {ld} depth_ratio {ratio}: total {tot:.6f} vs {want:.6f}"
+    assert math.isfinite(tot) and bool(torch.isfinite(gi).all()) and (ga is None or bool(torch.isfinite(ga).all())), line
+    assert abs(tot - want) <= 3e-5 * max(abs(want), 1e-3), line
+    assert abs(float(parts[0]) - float(l1o)) <= 3e-5 * max(float(l1o), 1e-3) and abs(float(parts[1]) - float(so)) <= 3e-5, line
+    gio = io.grad
+    assert float((gi - gio).abs().max()) <= 3e-4 * float(gio.abs().max()) + 1e-12, line
+    if use_reg:
+        # Compared where alpha > 0.  At a hole the reference's formulation leaves 0 / 0 on the depth and alpha channels and,
+        # where both x- or both y-neighbours of a pixel are holes (their points coincide at the camera centre, the cross product
+        # is exactly 0, F.normalize's backward is g / 1e-12), numbers of order 1e9 on the median channel -- on HOLE pixels only
+        # (d cross / d dy = dx x . = 0), which the rasterizer's backward never reads.  The fused kernel writes zeros there.
+        lit = (am[1] > 0)
+        gao = torch.nan_to_num(ao.grad, 0.0, 0.0, 0.0)
+        for c in range(7):
+            if not bool(lit.any()):
+                break
+            sc = float(gao[c][lit].abs().max())
+            err = float((ga[c] - gao[c])[lit].abs().max())
+            assert err <= 3e-3 * sc + 1e-10, (line, c, err, sc)
+    else:
+        assert ga is None or float(ga.abs().max()) == 0.0
     print("\n   " + line)
