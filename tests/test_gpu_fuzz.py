@@ -1,4 +1,4 @@
-"""Differential fuzz: 162 deterministic pseudo-random configurations (72 + 36 + 24 + 30 over the four tests) -- image sizes that are no multiple of the 16-pixel tile
+"""Differential fuzz: 178 deterministic pseudo-random configurations (72 + 36 + 24 + 30 + 16 over the five tests) -- image sizes that are no multiple of the 16-pixel tile
 (down to 1 x 1), 1 ... 600 Gaussians, SH degree 0 ... 3, every combination of the three recalled-behaviour flags, random
 background and scale modifier, jittered views, SH or precomputed colours, a share of extreme Gaussians (tests/test_gpu_degenerate.py's kinds) -- each
 through the operator and the C ABI against the fp64 oracle, with the fp32 oracle beside it as the yardstick of what single
@@ -406,3 +406,49 @@ def test_random_objective_against_the_oracles(gpu_device, seed):
     else:
         assert ga is None or float(ga.abs().max()) == 0.0
     print("\n   " + line)
+
+
+# ---- the optimiser step: FusedAdam against torch.optim.Adam over drawn shapes, step counts, learning rates and gradient scales ----
+@pytest.mark.parametrize("seed", list(range(400, 416)))
+def test_random_adam_against_torch(gpu_device, seed):
+    from gaussmart_amd.fused_adam import FusedAdam
+    dev = gpu_device
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    n = [1, 2, 63, 64, 65, 257, 1000, 4097, 20011][ri(0, 8)]
+    shapes = [(n, 3), (n, 1, 3), (n, [0, 3, 8, 15][ri(0, 3)], 3), (n, 1), (n, 2), (n, 4)]
+    shapes = [s for s in shapes if all(d > 0 for d in s)][: ri(1, 6)]
+    lrs = [float(10.0 ** (-6 + 5 * torch.rand(1, generator=g))) if ri(0, 5) else 0.0 for _ in shapes]
+    gexp = [float(-30 + 50 * torch.rand(1, generator=g)) for _ in shapes]            # gradient scale 1e-30 ... 1e20 per tensor
+    steps = ri(1, 40)
+    init = [torch.randn(s, generator=g) * float(10.0 ** (-3 + 6 * torch.rand(1, generator=g))) for s in shapes]
+    pa = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    pb = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    oa = FusedAdam([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(pa, lrs))], lr=0.0, eps=1e-15)
+    ob = torch.optim.Adam([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(pb, lrs))], lr=0.0, eps=1e-15,
+                          foreach=False, fused=False)
+    for it in range(steps):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            gr = torch.randn(a.shape, generator=g) * 10.0 ** gexp[i]
+            mode = ri(0, 5)
+            if mode == 0:
+                gr[::2] = 0                                   # invisible rows: zero gradient, the moments still decay
+            elif mode == 1:
+                gr.zero_()
+            a.grad, b.grad = gr.to(dev), gr.to(dev)
+            if mode == 2 and i == 0:                          # a parameter that sits this step out (replaced by a densification)
+                a.grad = b.grad = None
+        if ri(0, 3) == 0:
+            k = ri(0, len(shapes) - 1)
+            oa.param_groups[k]["lr"] = ob.param_groups[k]["lr"] = lrs[k] * float(torch.rand(1, generator=g))
+        oa.step(); ob.step()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert bool(torch.isfinite(a).all()) == bool(torch.isfinite(b).all())
+        tag = (seed, i, tuple(a.shape), lrs[i], gexp[i], steps)
+        torch.testing.assert_close(a, b, rtol=3e-6, atol=1e-7 * float(b.detach().abs().max()) + 1e-30, msg=lambda m: f"{tag}: {m}")
+        if a in oa.state and b in ob.state and "exp_avg" in ob.state[b]:
+            ea, eb = oa.state[a]["exp_avg"], ob.state[b]["exp_avg"]
+            torch.testing.assert_close(ea, eb, rtol=3e-6, atol=2e-6 * float(eb.abs().max()) + 1e-37, msg=lambda m: f"{tag} exp_avg: {m}")
+            va, vb = oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]
+            torch.testing.assert_close(va, vb, rtol=3e-6, atol=2e-6 * float(vb.abs().max()) + 1e-37, msg=lambda m: f"{tag} exp_avg_sq: {m}")
+            assert float(oa.state[a]["step"]) == float(ob.state[b]["step"])
