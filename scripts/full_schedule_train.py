@@ -243,6 +243,8 @@ def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=
         "all_finite_at_every_log_point": all(t[5] for t in trace),
         "world_size": world, "backend": (torch.distributed.get_backend() if world > 1 else None),
         "replicas_identical_at_every_log_point": all(replicas),
+        # sums of the raw bit patterns of the six parameter tensors: two runs of the same command must print the same six numbers
+        "final_parameter_checksum": [int(v) for v in vp.replica_checksum().tolist()],
         "row_scans_carried": R.STATS["row_scans_carried"],
         "trace_columns": ["iteration", "points", "seconds", "loss", "sh_degree", "finite"],
         "trace": trace,
