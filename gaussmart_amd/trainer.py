@@ -45,7 +45,8 @@ def _unit_gradient(t):
 def training_losses(render_pkg, gt_image, opt, iteration, viewpoint_cam=None, pipe=None, defer_value=False):
     """train.py:113-143.  On a HIP device the whole objective (L1 + SSIM + surface regularizers) is
     one fused autograd node (gaussmart_amd/fused_objective.py); on the host (CPU plumbing tests)
-    the stock torch formulation of the reference is used on the maps render() derived.
+    the stock torch formulation of the reference is used on the maps render() derived -- and on a device too when
+    `pipe.reference_objective` is set (then with utils/loss_utils.py's torch L1 + SSIM: the reference-shaped loop).
     (The diagnostics follow what the forward was asked to build: "dist_mean" reads 0 while lambda_dist = 0 -- the reference
     logs lambda_dist * mean there, i.e. 0 as well -- and "normal_mean" reads 0 while no regularizer is active.)"""
     image = render_pkg["render"]
@@ -72,6 +73,7 @@ def _use_factored_sh_grad(gaussians, pipe, render_fn, on_device):
     """The backward may leave dL/drgb [N,3] instead of the SH gradient tensors only when this module also performs the
     optimiser step with the kernel that understands it (FusedAdam.step_sh_factored) on the raw-parameter path."""
     return (on_device and render_fn is render and getattr(pipe, "factored_sh_grad", False)
+            and not getattr(pipe, "reference_objective", False)        # (that formulation reads the maps render() derives)
             and getattr(gaussians, "raster_state", None) is not None
             and getattr(pipe, "fused_activations", False) and isinstance(getattr(gaussians, "optimizer", None), FusedAdam))
 

@@ -175,3 +175,10 @@ def test_reference_objective_switch_keeps_the_torch_maps(monkeypatch):
         with pytest.raises(Stop):
             T.training_step(g, None, None, opt, pipe, None, 8000, render_fn=fake_render)
     assert seen == [False, True]
+    # ... and it wins over the factored path (whose forward builds no maps for torch to read)
+    pipe = PipelineParams()
+    pipe.reference_objective = True
+    g.raster_state, g.optimizer = object(), T.FusedAdam.__new__(T.FusedAdam)
+    assert not T._use_factored_sh_grad(g, pipe, T.render, True)
+    pipe.reference_objective = False
+    assert T._use_factored_sh_grad(g, pipe, T.render, True)
