@@ -300,6 +300,10 @@ def main():
     ap.add_argument("--cpu-gaussians", type=int, default=250_000)
     ap.add_argument("--cpu-full", action="store_true", help="CPU baseline on the whole frame, un-sampled (~2 min)")
     ap.add_argument("--forward-frames", type=int, default=50, help="inference frames (no_grad render) timed after the run")
+    ap.add_argument("--dropin-render", choices=("torch", "hip"), default="torch",
+                    help="--mode dropin: `torch` = render() as the reference writes it (torch activations, torch post-processing of "
+                         "allmap); `hip` = gaussmart_amd.gaussian_renderer.render with the activations fused into the operator and "
+                         "the derived maps from fused_surface_maps (same signature, same dictionary)")
     ap.add_argument("--dropin-adam", choices=("torch", "hip"), default="torch",
                     help="--mode dropin: `torch` = torch.optim.Adam as scene/gaussian_model.py:295 builds it; `hip` = "
                          "gaussmart_amd.fused_adam.FusedAdam (same class interface and state, one launch per step)")
@@ -384,6 +388,11 @@ def main():
             raise SystemExit("--mode dropin is the reference's single-GPU loop (it has no distributed code)")
         pipe.fused_activations = False
         pipe.factored_sh_grad = False
+        if args.dropin_render == "hip":
+            # a third optional line: `from gaussmart_amd.gaussian_renderer import render` -- the same
+            # signature and dictionary, the activations inside the operator's kernels and the five derived maps from one launch
+            pipe.fused_activations = True
+            pipe.fused_surface_maps = True
 
     target = GaussianModel(3, device=dev)
     target.create_from_params(perturb(params))
@@ -637,8 +646,9 @@ def main():
                        "tile_list_mean": round(D / tiles, 1), "entries_walked_per_pixel_mean": round(float(nc.mean()), 1),
                        "entries_walked_per_pixel_max": int(nc.max()),
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",
-                       "mode": args.mode + (" (reference-signature operator under a reference-shaped loop: torch activations, "
-                                            "torch post-processing, " + ("gaussmart_amd.loss_utils l1_loss / ssim (HIP)" if args.dropin_loss == "hip"
+                       "mode": args.mode + (" (reference-signature operator under a reference-shaped loop: " +
+                                            ("activations in the operator, derived maps from one HIP launch, " if args.dropin_render == "hip"
+                                             else "torch activations, torch post-processing, ") + ("gaussmart_amd.loss_utils l1_loss / ssim (HIP)" if args.dropin_loss == "hip"
                                                                         else "torch L1 + SSIM") +
                                             ", " + ("fused_adam.FusedAdam" if args.dropin_adam == "hip" else "torch.optim.Adam") + ", one .item() per step)"
                                             if dropin else " (raw-parameter operator, fused objective, factored SH Adam)"),

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (import order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GSR_LIB_PATH: developer aid for same-box A/B runs of two builds of the library (scripts/ab_builds.sh)
 LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(_HERE, "lib", "libgsr_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 GSR_BUF_GEOM, GSR_BUF_BINNING, GSR_BUF_IMAGE, GSR_BUF_SCRATCH, GSR_BUF_SCRATCH2 = range(5)
 GSR_BUF_SYNC_SH = 100     # not a buffer: "the SH colour pass is about to be enqueued" (GSR_FLAG_DEFER_COLOR)
@@ -139,10 +139,16 @@ def lib():
         L.gsr_regularizer_backward.restype = C.c_int32
         L.gsr_regularizer_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float,
                                                C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
-        # (every symbol below is part of ABI 5: a library without one of them fails the version check above, so there are
+        # (every symbol below is part of ABI 5 / 6: a library without one of them fails the version check above, so there are
         # no per-symbol guards)
         L.gsr_regularizer_backward_partials.restype = C.c_int32
         L.gsr_regularizer_backward_partials.argtypes = L.gsr_regularizer_backward.argtypes[:-1] + [C.c_void_p, C.c_void_p]
+        L.gsr_surface_maps_forward.restype = C.c_int32
+        L.gsr_surface_maps_forward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                               C.c_float, C.c_void_p, C.c_void_p]
+        L.gsr_surface_maps_backward.restype = C.c_int32
+        L.gsr_surface_maps_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                                C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gsr_row_scan_job.restype = C.c_int32
         L.gsr_row_scan_job.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GsrRowScanJob)]
         L.gsr_backward_with_job.restype = C.c_int32

@@ -257,6 +257,140 @@ __global__ void __launch_bounds__(256) reg_bwd_kernel(RegParams p, const float* 
     dam[4 * HW + o] = -kn * sn.z;
 }
 
+// ---- the maps themselves (render()'s post-processing, gaussian_renderer/__init__.py:117-156) as one kernel each way ----------
+// For callers that want the reference's dictionary -- rend_normal, surf_depth, surf_normal as tensors -- instead of the fused
+// objective: out[0:3] = allmap[2:5] rotated to world space (n @ world_view[:3,:3].T), out[3] = surf_depth, out[4:7] =
+// depth_to_normal(surf_depth) * alpha.detach() in WORLD space (p.m = c2w[:3,:3] K^-1: the rays the reference builds,
+// utils/point_utils.py:9-24; the ray origin drops out of the differences).  The backward takes whatever gradients arrive for the
+// seven planes.  F.normalize's eps regime (|cross| <= 1e-12: a plain scaling by 1e12) is followed on both sides.
+struct MapRot { float a[9]; };        // world_view_transform[:3,:3], row-major: out_j = sum_i a[3 j + i] n_i
+
+__global__ void __launch_bounds__(256) maps_fwd_kernel(RegParams p, MapRot rot, const float* __restrict__ am,
+                                                       float* __restrict__ out) {
+    __shared__ float sd[RG_T + 2][RG_T + 3];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int tiles_x = (p.W + RG_T - 1) / RG_T;
+    int tile_x, tile_y;
+    if (!gsr_xcd_tile(tiles_x, (p.H + RG_T - 1) / RG_T, tile_x, tile_y)) return;
+    const int x0 = tile_x * RG_T, y0 = tile_y * RG_T;
+    const int x = x0 + tx, y = y0 + ty;
+    const size_t HW = (size_t)p.W * p.H;
+    const bool in_img = x < p.W && y < p.H;
+    const bool interior = in_img && x >= 1 && x <= p.W - 2 && y >= 1 && y <= p.H - 2;
+    const size_t o = in_img ? (size_t)y * p.W + x : 0;
+    float alpha = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    if (in_img) { alpha = am[HW + o]; n0 = am[2 * HW + o]; n1 = am[3 * HW + o]; n2 = am[4 * HW + o]; }
+    rg_stage_depth<1>(p, am, sd, x0, y0);
+    __syncthreads();
+    if (!in_img) return;
+    float3 sn = make_float3(0.f, 0.f, 0.f);
+    if (interior) {
+        const float3 ru = rg_ray(p, x, y + 1), rd = rg_ray(p, x, y - 1), rr = rg_ray(p, x + 1, y), rl = rg_ray(p, x - 1, y);
+        const float du = sd[ty + 2][tx + 1], dd = sd[ty][tx + 1], dr = sd[ty + 1][tx + 2], dl = sd[ty + 1][tx];
+        const float3 dx = make_float3(du * ru.x - dd * rd.x, du * ru.y - dd * rd.y, du * ru.z - dd * rd.z);
+        const float3 dy = make_float3(dr * rr.x - dl * rl.x, dr * rr.y - dl * rl.y, dr * rr.z - dl * rl.z);
+        const float3 c = rg_cross(dx, dy);
+        const float inv = 1.0f / fmaxf(sqrtf(c.x * c.x + c.y * c.y + c.z * c.z), 1e-12f);
+        sn = make_float3(c.x * inv * alpha, c.y * inv * alpha, c.z * inv * alpha);
+    }
+    out[o] = rot.a[0] * n0 + rot.a[1] * n1 + rot.a[2] * n2;
+    out[HW + o] = rot.a[3] * n0 + rot.a[4] * n1 + rot.a[5] * n2;
+    out[2 * HW + o] = rot.a[6] * n0 + rot.a[7] * n1 + rot.a[8] * n2;
+    out[3 * HW + o] = sd[ty + 1][tx + 1];
+    out[4 * HW + o] = sn.x; out[5 * HW + o] = sn.y; out[6 * HW + o] = sn.z;
+}
+
+__global__ void __launch_bounds__(256) maps_bwd_kernel(RegParams p, MapRot rot, const float* __restrict__ am,
+                                                       const float* __restrict__ gout, float* __restrict__ dam) {
+    __shared__ float sd[RG_T + 4][RG_T + 5];          // surf_depth, halo 2
+    __shared__ float sg[6][RG_T + 2][RG_T + 3];       // dL/ddx, dL/ddy of every pixel, halo 1
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int tiles_x = (p.W + RG_T - 1) / RG_T;
+    int tile_x, tile_y;
+    if (!gsr_xcd_tile(tiles_x, (p.H + RG_T - 1) / RG_T, tile_x, tile_y)) return;
+    const int x0 = tile_x * RG_T, y0 = tile_y * RG_T;
+    const size_t HW = (size_t)p.W * p.H;
+    constexpr int R1 = RG_T + 2;
+    float p1_alpha[2], p1_g0[2], p1_g1[2], p1_g2[2];
+    bool p1_in[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        const int r = i / R1, q = i - r * R1;
+        const int y = y0 + r - 1, x = x0 + q - 1;
+        p1_in[u] = i < R1 * R1 && x >= 1 && x <= p.W - 2 && y >= 1 && y <= p.H - 2;
+        p1_alpha[u] = 0.f; p1_g0[u] = 0.f; p1_g1[u] = 0.f; p1_g2[u] = 0.f;
+        if (p1_in[u]) {
+            const size_t o = (size_t)y * p.W + x;
+            p1_alpha[u] = am[HW + o]; p1_g0[u] = gout[4 * HW + o]; p1_g1[u] = gout[5 * HW + o]; p1_g2[u] = gout[6 * HW + o];
+        }
+    }
+    const int fx = x0 + tx, fy = y0 + ty;
+    const bool f_in = fx < p.W && fy < p.H;
+    const size_t fo = f_in ? (size_t)fy * p.W + fx : 0;
+    float fD = 0.f, fA = 1.f, fmed = 0.f, g_rn0 = 0.f, g_rn1 = 0.f, g_rn2 = 0.f, g_sd_direct = 0.f;
+    if (f_in) {
+        fD = am[fo]; fA = am[HW + fo]; fmed = am[5 * HW + fo];
+        g_rn0 = gout[fo]; g_rn1 = gout[HW + fo]; g_rn2 = gout[2 * HW + fo]; g_sd_direct = gout[3 * HW + fo];
+    }
+    rg_stage_depth<2>(p, am, sd, x0, y0);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        if (i >= R1 * R1) continue;
+        const int r = i / R1, q = i - r * R1;
+        const int y = y0 + r - 1, x = x0 + q - 1;
+        float3 gdx = make_float3(0.f, 0.f, 0.f), gdy = gdx;
+        if (p1_in[u]) {
+            const float3 ru = rg_ray(p, x, y + 1), rd = rg_ray(p, x, y - 1), rr = rg_ray(p, x + 1, y), rl = rg_ray(p, x - 1, y);
+            const float du = sd[r + 2][q + 1], dd = sd[r][q + 1], dr = sd[r + 1][q + 2], dl = sd[r + 1][q];
+            const float3 dx = make_float3(du * ru.x - dd * rd.x, du * ru.y - dd * rd.y, du * ru.z - dd * rd.z);
+            const float3 dy = make_float3(dr * rr.x - dl * rl.x, dr * rr.y - dl * rl.y, dr * rr.z - dl * rl.z);
+            const float3 c = rg_cross(dx, dy);
+            const float len = sqrtf(c.x * c.x + c.y * c.y + c.z * c.z);
+            const float a = p1_alpha[u];
+            const float3 g = make_float3(p1_g0[u] * a, p1_g1[u] * a, p1_g2[u] * a);      // (alpha detached)
+            float3 gc;
+            if (len > 1e-12f) {
+                const float il = 1.0f / len;
+                const float3 s = make_float3(c.x * il, c.y * il, c.z * il);
+                const float sg_ = s.x * g.x + s.y * g.y + s.z * g.z;
+                gc = make_float3((g.x - s.x * sg_) * il, (g.y - s.y * sg_) * il, (g.z - s.z * sg_) * il);
+            } else {
+                gc = make_float3(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f);                   // c / max(|c|, eps): the eps regime
+            }
+            gdx = rg_cross(dy, gc);
+            gdy = rg_cross(gc, dx);
+        }
+        sg[0][r][q] = gdx.x; sg[1][r][q] = gdx.y; sg[2][r][q] = gdx.z;
+        sg[3][r][q] = gdy.x; sg[4][r][q] = gdy.y; sg[5][r][q] = gdy.z;
+    }
+    __syncthreads();
+    if (!f_in) return;
+    const int x = fx, y = fy;
+    const size_t o = fo;
+    const int r = ty + 1, q = tx + 1;
+    float3 gP;
+    gP.x = sg[0][r - 1][q] - sg[0][r + 1][q] + sg[3][r][q - 1] - sg[3][r][q + 1];
+    gP.y = sg[1][r - 1][q] - sg[1][r + 1][q] + sg[4][r][q - 1] - sg[4][r][q + 1];
+    gP.z = sg[2][r - 1][q] - sg[2][r + 1][q] + sg[5][r][q - 1] - sg[5][r][q + 1];
+    const float3 ray = rg_ray(p, x, y);
+    const float g_sd = gP.x * ray.x + gP.y * ray.y + gP.z * ray.z + g_sd_direct;
+    const float D = fD, A = fA, med = fmed;
+    const float e = D / A;
+    const bool e_ok = !(isnan(e) || isinf(e));
+    const float g_e = (1.f - p.depth_ratio) * g_sd;
+    // (where D / A is not finite -- alpha = 0 -- torch leaves 0 / 0 here; those pixels hold no splat and nobody reads them)
+    dam[o] = e_ok ? g_e / A : 0.f;
+    dam[HW + o] = e_ok ? -g_e * D / (A * A) : 0.f;
+    dam[5 * HW + o] = (isnan(med) || isinf(med)) ? 0.f : p.depth_ratio * g_sd;
+    dam[6 * HW + o] = 0.f;
+    dam[2 * HW + o] = rot.a[0] * g_rn0 + rot.a[3] * g_rn1 + rot.a[6] * g_rn2;
+    dam[3 * HW + o] = rot.a[1] * g_rn0 + rot.a[4] * g_rn1 + rot.a[7] * g_rn2;
+    dam[4 * HW + o] = rot.a[2] * g_rn0 + rot.a[5] * g_rn1 + rot.a[8] * g_rn2;
+}
+
 static int fill_params(RegParams& p, int H, int W, float depth_ratio, const float* kinv) {
     if (H <= 0 || W <= 0 || !kinv) { gsr_set_error("bad regularizer arguments"); return GSR_E_INVALID; }
     p.W = W; p.H = H; p.depth_ratio = depth_ratio;
@@ -298,6 +432,39 @@ extern "C" int32_t gsr_regularizer_backward_partials(const float* allmap, int32_
     dim3 grid(gsr_xcd_tile_grid(((W + RG_T - 1) / RG_T) * ((H + RG_T - 1) / RG_T)));
     hipLaunchKernelGGL(reg_bwd_kernel, grid, dim3(256), 0, s, p, allmap, lambda_normal, lambda_dist, grad_scale, d_allmap,
                        partials);
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}
+
+extern "C" int32_t gsr_surface_maps_forward(const float* allmap, int32_t H, int32_t W, const float* rays_world_host,
+                                            const float* rot_host, float depth_ratio, float* out7, gsr_stream_t stream_) {
+    RegParams p;
+    int rc = fill_params(p, H, W, depth_ratio, rays_world_host);
+    if (rc != GSR_OK) return rc;
+    if (!allmap || !rot_host || !out7) { gsr_set_error("bad surface-maps arguments"); return GSR_E_INVALID; }
+    MapRot rot;
+    for (int i = 0; i < 9; ++i) rot.a[i] = rot_host[i];
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    GsrProfileScope prof(GSR_K_REG_FWD, s);
+    dim3 grid(gsr_xcd_tile_grid(((W + RG_T - 1) / RG_T) * ((H + RG_T - 1) / RG_T)));
+    hipLaunchKernelGGL(maps_fwd_kernel, grid, dim3(256), 0, s, p, rot, allmap, out7);
+    GSR_LAUNCH_CHECK();
+    return GSR_OK;
+}
+
+extern "C" int32_t gsr_surface_maps_backward(const float* allmap, int32_t H, int32_t W, const float* rays_world_host,
+                                             const float* rot_host, float depth_ratio, const float* d_out7, float* d_allmap,
+                                             gsr_stream_t stream_) {
+    RegParams p;
+    int rc = fill_params(p, H, W, depth_ratio, rays_world_host);
+    if (rc != GSR_OK) return rc;
+    if (!allmap || !rot_host || !d_out7 || !d_allmap) { gsr_set_error("bad surface-maps arguments"); return GSR_E_INVALID; }
+    MapRot rot;
+    for (int i = 0; i < 9; ++i) rot.a[i] = rot_host[i];
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    GsrProfileScope prof(GSR_K_REG_BWD, s);
+    dim3 grid(gsr_xcd_tile_grid(((W + RG_T - 1) / RG_T) * ((H + RG_T - 1) / RG_T)));
+    hipLaunchKernelGGL(maps_bwd_kernel, grid, dim3(256), 0, s, p, rot, allmap, d_out7, d_allmap);
     GSR_LAUNCH_CHECK();
     return GSR_OK;
 }

@@ -30,6 +30,9 @@ class PipelineParams:
     # the reference's own formulation instead (render() derives the maps in torch, utils/loss_utils.py's L1 + SSIM, the two
     # regularizers as train.py:132-143) -- what a PYTHONPATH swap under the reference's train.py runs
     reference_objective: bool = False
+    # not in the reference: render()'s five derived maps (rend_normal, surf_depth, surf_normal, ...) from one HIP launch each way
+    # instead of the reference's torch post-processing (gaussian_renderer/__init__.py:117-156) -- same tensors, same gradients
+    fused_surface_maps: bool = False
 
 
 @dataclass

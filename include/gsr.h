@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 5   /* 5: BINNING carries row_count / slot_off / the scan workspace, 72-byte gradient rows, GsrRowScanJob */
+#define GSR_ABI_VERSION 6   /* 5: BINNING carries row_count / slot_off / the scan workspace, 72-byte gradient rows, GsrRowScanJob;
+                                6: gsr_surface_maps_forward / _backward */
 #define GSR_MAX_CHANNELS 64   /* widest per-pixel payload of gsr_forward / gsr_backward */
 
 typedef void* gsr_stream_t; /* hipStream_t */
@@ -280,6 +281,22 @@ int32_t gsr_regularizer_backward_partials(const float* allmap, int32_t H, int32_
                                           float depth_ratio, float lambda_normal, float lambda_dist,
                                           const float* grad_scale, float* d_allmap, float* partials,
                                           gsr_stream_t stream);
+
+/* The maps the reference's render() derives from allmap (gaussian_renderer/__init__.py:117-156, utils/point_utils.py:9-37) as
+ * TENSORS, for callers that keep the reference's own objective instead of gsr_regularizer_*:
+ *   out7[0:3] = allmap[2:5] @ world_view[:3,:3].T   (rend_normal, world space)      rot_host: HOST f32[9] = world_view[:3,:3]
+ *   out7[3]   = (1-r) nan_to_num(allmap[0] / allmap[1]) + r nan_to_num(allmap[5])   (surf_depth)
+ *   out7[4:7] = normalize(cross of the finite differences of the back-projected depth) * allmap[1], 0 on the border
+ *               (surf_normal, world space; alpha not differentiated)                rays_world_host: HOST f32[9] =
+ *               c2w[:3,:3] K^-1, ray(x,y) = that * [x,y,1]
+ * backward: d_allmap f32[7,H,W] from d_out7 f32[7,H,W] (every element of both read / written; rend_alpha = allmap[1] and
+ * rend_dist = allmap[6] are plain slices the caller differentiates itself).  At pixels with allmap[1] = 0 torch leaves 0 / 0
+ * on channels 0 and 1; this writes 0 (no splat covers such a pixel and gsr_backward never reads its gradient). */
+int32_t gsr_surface_maps_forward(const float* allmap, int32_t H, int32_t W, const float* rays_world_host,
+                                 const float* rot_host, float depth_ratio, float* out7, gsr_stream_t stream);
+int32_t gsr_surface_maps_backward(const float* allmap, int32_t H, int32_t W, const float* rays_world_host,
+                                  const float* rot_host, float depth_ratio, const float* d_out7, float* d_allmap,
+                                  gsr_stream_t stream);
 
 /* The whole training objective from the partials of gsr_loss_forward (and, when reg_partials is
  * non-NULL, gsr_regularizer_forward) in one tiny launch:
