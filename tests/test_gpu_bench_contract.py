@@ -47,3 +47,7 @@ def test_dropin_mode_and_evaluation_flags(gpu_device):
     assert drop["config"]["mode"].startswith("dropin") and drop["value"] > 0 and drop["with_all_seven_allmap_channels"] is None
     ev = _bench("--no-cpu-baseline", "--eval-flags")
     assert "lambda_normal 0" in ev["config"]["loss"] and ev["value"] > 0
+    # the drop-in loop after the optional edits of INTEGRATION.md section 1 (HIP l1_loss / ssim, FusedAdam, this repository's render())
+    swapped = _bench("--no-cpu-baseline", "--mode", "dropin", "--dropin-loss", "hip", "--dropin-adam", "hip", "--dropin-render", "hip")
+    mode = swapped["config"]["mode"]
+    assert "loss_utils" in mode and "FusedAdam" in mode and "derived maps from one HIP launch" in mode and swapped["value"] > 0
