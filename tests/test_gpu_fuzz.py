@@ -1,4 +1,4 @@
-"""Differential fuzz: 178 deterministic pseudo-random configurations (72 + 36 + 24 + 30 + 16 over the five tests) -- image sizes that are no multiple of the 16-pixel tile
+"""Differential fuzz: 198 deterministic pseudo-random configurations (72 + 36 + 24 + 30 + 16 + 20 over the six tests) -- image sizes that are no multiple of the 16-pixel tile
 (down to 1 x 1), 1 ... 600 Gaussians, SH degree 0 ... 3, every combination of the three recalled-behaviour flags, random
 background and scale modifier, jittered views, SH or precomputed colours, a share of extreme Gaussians (tests/test_gpu_degenerate.py's kinds) -- each
 through the operator and the C ABI against the fp64 oracle, with the fp32 oracle beside it as the yardstick of what single
@@ -452,3 +452,38 @@ def test_random_adam_against_torch(gpu_device, seed):
             va, vb = oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]
             torch.testing.assert_close(va, vb, rtol=3e-6, atol=2e-6 * float(vb.abs().max()) + 1e-37, msg=lambda m: f"{tag} exp_avg_sq: {m}")
             assert float(oa.state[a]["step"]) == float(ob.state[b]["step"])
+
+
+# ---- binning: tile lists, ranges and the reconstructed 64-bit keys bit for bit against NumPy's stable sort, on adversarial draws ----
+@pytest.mark.parametrize("seed", list(range(500, 520)))
+def test_random_binning_bit_exact(gpu_device, seed):
+    import numpy as np
+    from gaussmart_amd.synthetic import activate, make_scene
+    from test_gpu_rasterizer import _debug, _numpy_binning
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    w, h = SIZES[ri(0, len(SIZES) - 1)] if seed % 2 else [(640, 360), (333, 211), (1000, 64), (64, 1000), (512, 512)][ri(0, 4)]
+    n = [1, 7, 300, 4097, 20000, 60001][ri(0, 5)]
+    p, cam = make_scene(n, w, h, seed=seed, radius_px=float(2 + 12 * torch.rand(1, generator=g)))
+    a = activate(p)
+    kind = seed % 5
+    if kind == 0:                                   # every depth equal: both sort stages must be stable
+        a["means3D"][:, 2] = 5.0
+    elif kind == 1:                                 # a handful of depth values
+        a["means3D"][:, 2] = torch.round(a["means3D"][:, 2])
+    elif kind == 2:                                 # everything in one spot: one tile holds (nearly) every instance
+        a["means3D"][:, :2] = a["means3D"][:1, :2] + 1e-3 * torch.randn(n, 2, generator=g)
+    elif kind == 3 and n >= 7:                      # a few screen-filling splats among the others
+        a["scales"][: max(1, n // 50)] = 30.0
+    dbg = _debug(a, cam, gpu_device)
+    keys, plist, ranges, _ = _numpy_binning(dbg, w, h)
+    assert dbg["num_rendered"] == keys.size, (seed, dbg["num_rendered"], keys.size)
+    np.testing.assert_array_equal(dbg["point_list"].cpu().numpy().astype(np.uint32)[: keys.size], plist)
+    np.testing.assert_array_equal(dbg["ranges"].cpu().numpy().astype(np.uint32), ranges)
+    if keys.size:
+        pl = dbg["point_list"].cpu().numpy().astype(np.int64)[: keys.size]
+        tile_of = np.repeat(np.arange(ranges.shape[0]), (ranges[:, 1] - ranges[:, 0]).astype(np.int64))
+        dk = dbg["depth_key"].cpu().numpy().astype(np.uint32).astype(np.uint64)
+        np.testing.assert_array_equal((tile_of.astype(np.uint64) << np.uint64(32)) | dk[pl], keys)
+        rows = dbg["inst_row"].cpu().numpy().astype(np.int64)[: keys.size]
+        assert np.array_equal(np.sort(rows), np.arange(keys.size))
