@@ -1,4 +1,4 @@
-"""Differential fuzz: 198 deterministic pseudo-random configurations (72 + 36 + 24 + 30 + 16 + 20 over the six tests) -- image sizes that are no multiple of the 16-pixel tile
+"""Differential fuzz: 214 deterministic pseudo-random configurations (72 + 36 + 24 + 30 + 16 + 20 + 16 over the seven tests) -- image sizes that are no multiple of the 16-pixel tile
 (down to 1 x 1), 1 ... 600 Gaussians, SH degree 0 ... 3, every combination of the three recalled-behaviour flags, random
 background and scale modifier, jittered views, SH or precomputed colours, a share of extreme Gaussians (tests/test_gpu_degenerate.py's kinds) -- each
 through the operator and the C ABI against the fp64 oracle, with the fp32 oracle beside it as the yardstick of what single
@@ -487,3 +487,37 @@ def test_random_binning_bit_exact(gpu_device, seed):
         np.testing.assert_array_equal((tile_of.astype(np.uint64) << np.uint64(32)) | dk[pl], keys)
         rows = dbg["inst_row"].cpu().numpy().astype(np.int64)[: keys.size]
         assert np.array_equal(np.sort(rows), np.arange(keys.size))
+
+
+# ---- simple_knn.distCUDA2: mean squared distance to the three nearest neighbours against a k-d tree, on drawn point clouds ----
+@pytest.mark.parametrize("seed", list(range(600, 616)))
+def test_random_point_cloud_knn(gpu_device, seed):
+    import numpy as np
+    from scipy.spatial import cKDTree
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(seed)
+    n = int([4, 5, 63, 64, 65, 1000, 1025, 30000, 100003][rng.integers(0, 9)])
+    scale = float(10.0 ** rng.uniform(-4, 4))
+    kind = seed % 6
+    if kind == 0:
+        pts = rng.normal(size=(n, 3))
+    elif kind == 1:       # a line (Morton boxes degenerate to one axis)
+        pts = np.c_[rng.uniform(-1, 1, size=n), np.zeros(n), np.zeros(n)]
+    elif kind == 2:       # many exact duplicates
+        pts = rng.integers(0, max(2, n // 8), size=(n, 3)).astype(np.float64)
+    elif kind == 3:       # two far-apart clusters of very different density
+        pts = np.r_[rng.normal(size=(n // 2, 3)) * 1e-3, rng.normal(size=(n - n // 2, 3)) + 50.0]
+    elif kind == 4:       # a plane plus outliers
+        pts = np.c_[rng.uniform(-1, 1, size=(n, 2)), np.zeros(n)]
+        pts[:: max(1, n // 7)] += rng.normal(size=pts[:: max(1, n // 7)].shape) * 20
+    else:                 # a thin shell
+        v = rng.normal(size=(n, 3)); pts = v / np.linalg.norm(v, axis=1, keepdims=True)
+    pts = (pts * scale).astype(np.float32)
+    out = distCUDA2(torch.from_numpy(pts).to(gpu_device)).cpu().numpy().astype(np.float64)
+    p64 = pts.astype(np.float64)
+    d, _ = cKDTree(p64).query(p64, k=4)
+    ref = (d[:, 1:] ** 2).mean(1)
+    # fp32 differences of coordinates ~scale: absolute floor from the rounding of (a - b)^2 at that magnitude
+    floor = 3 * (float(np.abs(pts).max()) * 2.0 ** -23) ** 2 * 8
+    assert np.all(np.isfinite(out))
+    np.testing.assert_allclose(out, ref, rtol=5e-5, atol=floor, err_msg=f"seed {seed} n {n} kind {kind} scale {scale:.2e}")
