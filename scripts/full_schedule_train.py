@@ -64,7 +64,7 @@ def all_finite(model, report=None):
 
 def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=None, quiet=False, model_out=None,
         start_fraction=1.0, grad_threshold=None, watch_from=None,
-        lambda_normal=None, lambda_dist=None, depth_ratio=None, white_background=False, mode="fused"):
+        lambda_normal=None, lambda_dist=None, depth_ratio=None, white_background=False, mode="fused", profile_tail=0):
     """-> summary dict.  `schedule_iterations`: opt.iterations (the lr schedule's horizon and the one iteration that
     takes no optimiser step); default = `iterations`, i.e. the run IS the whole schedule."""
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -180,7 +180,21 @@ def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=
         prev.clear()
         prev.update(cur)
 
+    prof = {}
+
     def on_iteration(it):
+        if profile_tail and it == iterations - profile_tail:      # per-kernel averages of the last iterations (HIP events of the
+            from gaussmart_amd import _lib                        # library's opt-in profiler: ~5 us of timeline per bracket)
+            vp.finish(); torch.cuda.synchronize()
+            _lib.profile_reset(); _lib.profile_enable(True)
+        if profile_tail and it == iterations:
+            from gaussmart_amd import _lib
+            vp.finish(); torch.cuda.synchronize()
+            _lib.profile_enable(False)
+            prof.update({k: [round(ms / n, 4), n] for k, (ms, n) in _lib.profile_read().items() if n})
+            if not quiet:
+                print("   kernel ms per launch over the last %d iterations: " % profile_tail +
+                      ", ".join(f"{k} {v[0]} (x{v[1] / profile_tail:g})" for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0] * kv[1][1])), flush=True)
         if watch_from is not None and it >= watch_from:
             watch(it)
         if it % log_every == 0 or it in marks:
@@ -244,6 +258,7 @@ def run(preset, iterations, views, log_every, seed, extent, schedule_iterations=
         "world_size": world, "backend": (torch.distributed.get_backend() if world > 1 else None),
         "replicas_identical_at_every_log_point": all(replicas),
         # sums of the raw bit patterns of the six parameter tensors: two runs of the same command must print the same six numbers
+        "kernel_ms_per_launch_tail": prof or None,
         "final_parameter_checksum": [int(v) for v in vp.replica_checksum().tolist()],
         "row_scans_carried": R.STATS["row_scans_carried"],
         "trace_columns": ["iteration", "points", "seconds", "loss", "sh_degree", "finite"],
@@ -272,13 +287,14 @@ def main(argv=None):
     ap.add_argument("--lambda-dist", type=float, default=None)
     ap.add_argument("--depth-ratio", type=float, default=None)
     ap.add_argument("--white-background", action="store_true")
+    ap.add_argument("--profile-tail", type=int, default=0, help="per-kernel launch averages over the last K iterations")
     ap.add_argument("--watch-from", type=int, default=None, help="diagnostic: from this iteration on, check every iteration and "
                     "print the first Gaussian that turns non-finite, before and after")
     ap.add_argument("--out", default=None)
     a = ap.parse_args(argv)
     s = run(a.preset, a.iterations, a.views, a.log_every, a.seed, a.extent, a.schedule_iterations,
             start_fraction=a.start_fraction, grad_threshold=a.grad_threshold, watch_from=a.watch_from,
-            lambda_normal=a.lambda_normal, lambda_dist=a.lambda_dist, depth_ratio=a.depth_ratio, white_background=a.white_background, mode=a.mode)
+            lambda_normal=a.lambda_normal, lambda_dist=a.lambda_dist, depth_ratio=a.depth_ratio, white_background=a.white_background, mode=a.mode, profile_tail=a.profile_tail)
     line = {k: v for k, v in s.items() if k != "trace"}
     if int(os.environ.get("RANK", "0")) == 0:
         print(json.dumps(line))
